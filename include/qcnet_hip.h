@@ -1,0 +1,113 @@
+/*
+ * qcnet_hip.h — C ABI of libqcnet_hip.so, the MI355X (gfx950) implementation of the QCNet /
+ * TempEnsLearnAgg graph-attention hot path.
+ *
+ * The reference (KaiYin77/TempEnSLearnAgg-QCNet) has no FFI of its own: its native work is delegated to
+ * torch_cluster / torch_geometric / ATen.  Each entry point below therefore cites the
+ * reference call site whose native work it replaces.
+ *
+ * Conventions
+ *   - every function returns an int status: QCN_OK (0) or a negative QCN_ERR_* code; nothing throws;
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every buffer
+ *     (outputs and workspaces), nothing is allocated or freed behind the ABI;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous on it and no call synchronises;
+ *   - feature width is fixed: C = 128 channels = H (8 heads) x D (16), the reference's AV2 configuration
+ *     (predictors/qcnet_sliding.py:422,433-434); other widths return QCN_ERR_UNSUPPORTED;
+ *   - index tensors at the API boundary are int64 (PyTorch / PyG convention); CSR arrays are int32.
+ */
+#ifndef QCNET_HIP_H
+#define QCNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QCN_OK 0
+#define QCN_ERR_INVALID_ARGUMENT (-1)
+#define QCN_ERR_UNSUPPORTED (-2)
+#define QCN_ERR_WORKSPACE_TOO_SMALL (-3)
+#define QCN_ERR_LAUNCH_FAILED (-4)
+
+#define QCN_CHANNELS 128
+#define QCN_HEADS 8
+#define QCN_HEAD_DIM 16
+
+/* Library version (major*10000 + minor*100 + patch) and status strings. */
+int qcn_version(void);
+const char *qcn_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------------
+ * G1 / G2 — radius search.  Replaces torch_cluster.radius / radius_graph
+ *   (modules/qcnet_agent_encoder.py:158,168; modules/qcnet_map_encoder.py:141;
+ *    modules/qcnet_decoder.py:174,194; modules/temporal_aggregate.py:175,195).
+ *
+ * For every y row (ascending) the x rows of the same example are scanned in ascending index order; a
+ * pair is a hit when the fp32 chain  d = dx*dx; d = fma(dy, dy, d) [; d = fma(dz, dz, d)]  is < r2.
+ * The scan of a y row stops after `max_num_neighbors` hits.  A hit is EMITTED unless
+ *   drop_self != 0 and x index == y index            (radius_graph(loop=False) self-pair removal), or
+ *   mask_x != NULL and mask_x[x index] == 0, or mask_y != NULL and mask_y[y index] == 0
+ *                                                    (the boolean column filters the modules apply right
+ *                                                     after the search, e.g. qcnet_agent_encoder.py:160,170).
+ * Filters never change which hits count towards the cap, exactly like filtering after the search.
+ * Two passes: qcn_radius_count writes the emitted count per y row; the caller turns it into an exclusive
+ * scan `offset` (qcn_exclusive_scan_i32) and allocates E = offset[n_y]; qcn_radius_fill writes
+ * row[e] = y index, col[e] = x index (int64), grouped by ascending y, x ascending inside a group.
+ * ptr_x / ptr_y: int64 [num_examples + 1] example boundaries (sorted batch vectors, as bucketize gives).
+ * dim is 2 or 3.
+ */
+int qcn_radius_count(const float *x, const float *y, const int64_t *ptr_x, const int64_t *ptr_y,
+                     int64_t num_examples, int64_t n_y, int dim, float r2, int max_num_neighbors,
+                     int drop_self, const uint8_t *mask_x, const uint8_t *mask_y,
+                     int32_t *count, void *stream);
+int qcn_radius_fill(const float *x, const float *y, const int64_t *ptr_x, const int64_t *ptr_y,
+                    int64_t num_examples, int64_t n_y, int dim, float r2, int max_num_neighbors,
+                    int drop_self, const uint8_t *mask_x, const uint8_t *mask_y,
+                    const int64_t *offset, int64_t *row, int64_t *col, void *stream);
+
+/* Exclusive prefix sum of int32 counts into int64 offsets [n + 1] (offset[n] = total).
+ * Replaces the masked_select compaction inside torch_cluster's radius op.  Workspace: query with
+ * qcn_scan_workspace_bytes(n). */
+size_t qcn_scan_workspace_bytes(int64_t n);
+int qcn_exclusive_scan_i32(const int32_t *count, int64_t n, int64_t *offset, void *workspace,
+                           size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3 — destination-sorted CSR of an edge list.  Replaces the per-call index_select / scatter indexing PyG's
+ * MessagePassing.propagate does on the raw COO edge_index (layers/attention_layer.py:118).
+ *   src, dst : int64 [E] (edge_index rows 0 / 1);  0 <= dst < n_dst
+ *   rowptr   : int32 [n_dst + 1];  col : int32 [E] source node per CSR slot;
+ *   eid      : int32 [E] original edge id per CSR slot (stable: ascending inside a destination).
+ */
+size_t qcn_csr_workspace_bytes(int64_t num_edges, int64_t n_dst);
+int qcn_csr_build(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst,
+                  int32_t *rowptr, int32_t *col, int32_t *eid, void *workspace, size_t workspace_bytes,
+                  void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * A3 — fused gather + segment softmax + weighted scatter-add of AttentionLayer.message / PyG propagate /
+ * PyG softmax (layers/attention_layer.py:87-101,118):
+ *   for dst i, edges e=(j->i):  k_e = k[j] + kr[e],  v_e = v[j] + vr[e],
+ *   s_e,h = (q[i,h,:] . k_e[h,:]) * D^-0.5,  a_e,h = exp(s - max_i) / (sum_i exp(s - max_i) + 1e-16),
+ *   out[i,h,:] = sum_e a_e,h * v_e[h,:]            (0 for destinations without edges)
+ *   q [n_dst,128]; k, v [n_src,128]; kr, vr [E,128] indexed by ORIGINAL edge id (both NULL when the layer
+ *   has no positional embedding, layers/attention_layer.py:94); rowptr/col/eid from qcn_csr_build
+ *   (eid == NULL means kr/vr rows are already in CSR order); out [n_dst,128].
+ */
+int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, const float *kr, const float *vr,
+                     const int32_t *rowptr, const int32_t *col, const int32_t *eid,
+                     int64_t n_dst, int64_t n_src, int64_t num_edges, float *out, void *stream);
+
+/* Optional per-launch timing of qcn_attn_fwd_* with hipEvents on the launch stream (bench.py roofline leg).
+ * qcn_prof_enable(1) starts recording, qcn_prof_collect synchronises the recorded events and returns the
+ * number of launches, the summed kernel milliseconds and the summed algorithmic bytes
+ * (2064*E + 1024*n_dst with pos-emb, 1040*E + 1024*n_dst without), then clears the log. */
+int qcn_prof_enable(int on);
+int qcn_prof_collect(int64_t *launches_host, double *millis_host, double *alg_bytes_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QCNET_HIP_H */

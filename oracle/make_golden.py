@@ -1,0 +1,132 @@
+"""Generates tests/golden/ref_*.npz from the reference's own Python sources (build container only).
+
+CPU ORACLE tooling — test infrastructure, never the product.  /root/reference does not exist on the
+GPU box, so this script is run here once and its small outputs are committed as data fixtures.
+
+What can be imported from /root/reference (ordinary pure-torch files, loaded by file path):
+  utils/weight_init.py, utils/geometry.py, layers/fourier_embedding.py, layers/mlp_layer.py
+They do ``from utils import weight_init``; the package ``utils/__init__.py`` would drag in
+``utils/graph.py`` → ``torch_geometric`` (not installed), so a namespace module named ``utils`` is
+populated with the reference's *own* functions from those two files.  Nothing of torch_geometric /
+torch_cluster is imitated: ``layers/attention_layer.py`` and ``modules/*`` therefore stay un-importable
+and their rows stay "parity unpinned" (SURVEY.md §8(c)).
+
+Usage:  python oracle/make_golden.py
+"""
+import importlib.util
+import math
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = '/root/reference'
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+
+def _load(name: str, path: str):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    wi = _load('_ref_weight_init', os.path.join(REF, 'utils', 'weight_init.py'))
+    geo = _load('_ref_geometry', os.path.join(REF, 'utils', 'geometry.py'))
+    ns = types.ModuleType('utils')
+    ns.weight_init = wi.weight_init
+    ns.angle_between_2d_vectors = geo.angle_between_2d_vectors
+    ns.wrap_angle = geo.wrap_angle
+    saved = sys.modules.get('utils')
+    sys.modules['utils'] = ns
+    try:
+        fe = _load('_ref_fourier_embedding', os.path.join(REF, 'layers', 'fourier_embedding.py'))
+        mlp = _load('_ref_mlp_layer', os.path.join(REF, 'layers', 'mlp_layer.py'))
+    finally:
+        if saved is not None:
+            sys.modules['utils'] = saved
+        else:
+            del sys.modules['utils']
+    return wi, geo, fe, mlp
+
+
+def _perturb(module: torch.nn.Module, gen: torch.Generator) -> None:
+    """weight_init leaves every bias at 0 and every LayerNorm at identity, which would hide bias /
+    affine bugs — move all of them off their trivial values (deterministically)."""
+    with torch.no_grad():
+        for name, prm in module.named_parameters():
+            if prm.dim() == 1:
+                prm.add_(torch.randn(prm.shape, generator=gen) * 0.1)
+            elif 'freqs' in name:
+                prm.copy_(torch.randn(prm.shape, generator=gen) * 0.05)
+
+
+def main() -> None:
+    os.makedirs(OUT, exist_ok=True)
+    wi, geo, fe, mlp = load_reference()
+    gen = torch.Generator().manual_seed(1234)
+    torch.manual_seed(1234)
+    blobs = {}
+
+    # ---- geometry (utils/geometry.py:19-23, 47-51)
+    ctr = torch.randn(257, 2, generator=gen)
+    nbr = torch.randn(257, 2, generator=gen) * 30.0
+    nbr[:5] = 0.0                                            # atan2(0, 0) rows
+    ang = (torch.rand(513, generator=gen) - 0.5) * 40.0
+    ang[:4] = torch.tensor([math.pi, -math.pi, 0.0, 3 * math.pi])
+    blobs['geo_ctr'], blobs['geo_nbr'], blobs['geo_angle_in'] = ctr, nbr, ang
+    blobs['geo_angle_between'] = geo.angle_between_2d_vectors(ctr, nbr)
+    blobs['geo_wrap'] = geo.wrap_angle(ang)
+
+    # ---- FourierEmbedding (layers/fourier_embedding.py) for every input_dim the path uses
+    for in_dim, n_rows, n_cat in ((0, 19, 2), (1, 33, 2), (2, 40, 0), (3, 65, 0), (3, 21, 1), (4, 50, 1), (4, 37, 0)):
+        m = fe.FourierEmbedding(input_dim=in_dim, hidden_dim=128, num_freq_bands=64).eval()
+        _perturb(m, gen)
+        tag = 'fe%d_c%d' % (in_dim, n_cat)
+        cont = None
+        if in_dim:
+            cont = torch.randn(n_rows, in_dim, generator=gen) * torch.tensor([40.0, 1.5, 1.5, 5.0][:in_dim])
+        cats = [torch.randn(n_rows, 128, generator=gen) * 0.05 for _ in range(n_cat)] or None
+        with torch.no_grad():
+            out = m(continuous_inputs=cont, categorical_embs=cats)
+        for k, v in m.state_dict().items():
+            blobs['%s.sd.%s' % (tag, k)] = v
+        if cont is not None:
+            blobs[tag + '.cont'] = cont
+        for i, c in enumerate(cats or []):
+            blobs['%s.cat%d' % (tag, i)] = c
+        blobs[tag + '.out'] = out
+
+    # ---- MLPLayer (layers/mlp_layer.py) for the decoder head widths (modules/qcnet_decoder.py:117-138)
+    for out_dim in (1, 40, 120):
+        m = mlp.MLPLayer(input_dim=128, hidden_dim=128, output_dim=out_dim).eval()
+        _perturb(m, gen)
+        x = torch.randn(23, 6, 128, generator=gen)
+        with torch.no_grad():
+            y = m(x)
+        tag = 'mlp%d' % out_dim
+        for k, v in m.state_dict().items():
+            blobs['%s.sd.%s' % (tag, k)] = v
+        blobs[tag + '.x'], blobs[tag + '.out'] = x, y
+
+    # ---- weight_init statistics (utils/weight_init.py:17-82): bounds / constants only, not the RNG stream
+    lin = torch.nn.Linear(128, 384)
+    wi.weight_init(lin)
+    blobs['wi_linear_absmax'] = lin.weight.detach().abs().max()
+    blobs['wi_linear_bias_absmax'] = lin.bias.detach().abs().max()
+    gru = torch.nn.GRU(128, 128)
+    wi.weight_init(gru)
+    whh = gru.weight_hh_l0.detach().chunk(3, 0)
+    blobs['wi_gru_hh_orth_err'] = max((w @ w.t() - torch.eye(128)).abs().max() for w in whh)
+    blobs['wi_gru_bias_absmax'] = max(gru.bias_ih_l0.detach().abs().max(), gru.bias_hh_l0.detach().abs().max())
+
+    np.savez_compressed(os.path.join(OUT, 'ref_layers.npz'),
+                        **{k: (v.detach().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in blobs.items()})
+    print('wrote %d arrays to %s' % (len(blobs), os.path.join(OUT, 'ref_layers.npz')))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,70 @@
+"""ctypes binding of libqcnet_hip.so (the C ABI declared in include/qcnet_hip.h).
+
+The library is the product: there is no CPU or eager fallback.  If the shared object is missing the
+import of any op raises immediately with the build command.
+"""
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libqcnet_hip.so')
+
+_lib = None
+
+
+class QcnError(RuntimeError):
+    pass
+
+
+def _declare(lib) -> None:
+    P = c_void_p
+    lib.qcn_version.restype = c_int
+    lib.qcn_version.argtypes = []
+    lib.qcn_status_string.restype = ctypes.c_char_p
+    lib.qcn_status_string.argtypes = [c_int]
+    radius_common = [P, P, P, P, c_int64, c_int64, c_int, c_float, c_int, c_int, P, P]
+    lib.qcn_radius_count.restype = c_int
+    lib.qcn_radius_count.argtypes = radius_common + [P, P]
+    lib.qcn_radius_fill.restype = c_int
+    lib.qcn_radius_fill.argtypes = radius_common + [P, P, P, P]
+    lib.qcn_scan_workspace_bytes.restype = c_size_t
+    lib.qcn_scan_workspace_bytes.argtypes = [c_int64]
+    lib.qcn_exclusive_scan_i32.restype = c_int
+    lib.qcn_exclusive_scan_i32.argtypes = [P, c_int64, P, P, c_size_t, P]
+    lib.qcn_csr_workspace_bytes.restype = c_size_t
+    lib.qcn_csr_workspace_bytes.argtypes = [c_int64, c_int64]
+    lib.qcn_csr_build.restype = c_int
+    lib.qcn_csr_build.argtypes = [P, P, c_int64, c_int64, P, P, P, P, c_size_t, P]
+    lib.qcn_attn_fwd_f32.restype = c_int
+    lib.qcn_attn_fwd_f32.argtypes = [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, P]
+    lib.qcn_prof_enable.restype = c_int
+    lib.qcn_prof_enable.argtypes = [c_int]
+    lib.qcn_prof_collect.restype = c_int
+    lib.qcn_prof_collect.argtypes = [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
+
+
+EXPORTED_SYMBOLS = (
+    'qcn_version', 'qcn_status_string', 'qcn_radius_count', 'qcn_radius_fill', 'qcn_scan_workspace_bytes',
+    'qcn_exclusive_scan_i32', 'qcn_csr_workspace_bytes', 'qcn_csr_build', 'qcn_attn_fwd_f32',
+    'qcn_prof_enable', 'qcn_prof_collect',
+)
+
+
+def lib():
+    """The loaded library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise QcnError('libqcnet_hip.so not found at %s — build it with `make -C %s` '
+                           '(or `python -c "import __graft_entry__ as g; g.build()"`); there is no fallback path.'
+                           % (LIB_PATH, os.path.dirname(LIB_PATH)))
+        handle = ctypes.CDLL(LIB_PATH)
+        _declare(handle)
+        _lib = handle
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        raise QcnError('%s failed: %s (status %d)' % (what, lib().qcn_status_string(status).decode(), status))

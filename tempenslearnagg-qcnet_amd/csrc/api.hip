@@ -1,0 +1,15 @@
+#include "common.hip.h"
+
+extern "C" int qcn_version(void) { return 100; }
+
+extern "C" const char *qcn_status_string(int status)
+{
+    switch (status) {
+    case QCN_OK: return "ok";
+    case QCN_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case QCN_ERR_UNSUPPORTED: return "unsupported shape or size";
+    case QCN_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+    case QCN_ERR_LAUNCH_FAILED: return "HIP launch failed";
+    default: return "unknown status";
+    }
+}

@@ -1,0 +1,141 @@
+"""Scenario containers for the QCNet hot path.
+
+The reference feeds its modules PyG ``HeteroData`` / ``Batch`` objects
+(``datasets/argoverse_v2_dataset.py:519-521`` builds one per scenario, the PyG
+``DataLoader`` collates them).  PyG is not part of this stack, so these two small
+classes give the modules the exact access pattern they use:
+
+* ``data['agent']['position']``, ``data['map_point', 'to', 'map_polygon']['edge_index']``
+  (``modules/qcnet_map_encoder.py:96-144``),
+* ``data.num_graphs`` and ``isinstance(data, Batch)`` switches
+  (``modules/qcnet_agent_encoder.py:148-157``, ``modules/qcnet_decoder.py:174-199``).
+
+Collation follows PyG's rule: node stores are concatenated, ``edge_index`` of a
+``(src, rel, dst)`` store is offset by the cumulative node counts of ``src`` / ``dst``,
+``num_nodes`` is summed, and every node store gains ``batch`` and ``ptr`` vectors.
+"""
+from typing import Any, Dict, Iterable, List, Tuple, Union
+
+import torch
+
+Key = Union[str, Tuple[str, str, str]]
+
+# Per-scenario scalar entries that collation turns into a per-graph tensor / list.
+_PER_GRAPH_KEYS = ('av_index',)
+
+
+class HeteroData:
+    """One scenario: a dict of node stores (str keys) and edge stores (3-tuple keys)."""
+
+    def __init__(self, stores: Dict[Key, Dict[str, Any]] = None) -> None:
+        self._stores: Dict[Key, Dict[str, Any]] = {}
+        for key, store in (stores or {}).items():
+            if isinstance(store, dict):
+                self._stores[key] = dict(store)
+            else:  # global attribute such as scenario_id
+                self._stores[key] = store
+
+    def __getitem__(self, key) -> Dict[str, Any]:
+        if isinstance(key, list):
+            key = tuple(key)
+        if key not in self._stores:
+            self._stores[key] = {}
+        return self._stores[key]
+
+    def __setitem__(self, key, value) -> None:
+        self._stores[key] = value
+
+    def __contains__(self, key) -> bool:
+        return key in self._stores
+
+    def keys(self) -> Iterable[Key]:
+        return self._stores.keys()
+
+    @property
+    def node_types(self) -> List[str]:
+        return [k for k, v in self._stores.items() if isinstance(k, str) and isinstance(v, dict)]
+
+    @property
+    def edge_types(self) -> List[Tuple[str, str, str]]:
+        return [k for k in self._stores if isinstance(k, tuple)]
+
+    def _map(self, fn):
+        out = self.__class__.__new__(self.__class__)
+        out.__dict__.update({k: v for k, v in self.__dict__.items() if k != '_stores'})
+        out._stores = {}
+        for key, store in self._stores.items():
+            if isinstance(store, dict):
+                out._stores[key] = {n: (fn(v) if torch.is_tensor(v) else v) for n, v in store.items()}
+            else:
+                out._stores[key] = fn(store) if torch.is_tensor(store) else store
+        return out
+
+    def to(self, device, non_blocking: bool = False):
+        return self._map(lambda t: t.to(device, non_blocking=non_blocking))
+
+    def cpu(self):
+        return self.to('cpu')
+
+    def clone(self):
+        return self._map(lambda t: t.clone())
+
+
+class Batch(HeteroData):
+    """A collated list of scenarios (PyG ``Batch.from_data_list`` semantics)."""
+
+    def __init__(self, stores=None, num_graphs: int = 1) -> None:
+        super().__init__(stores)
+        self.num_graphs = num_graphs
+
+    @classmethod
+    def from_data_list(cls, data_list: List[HeteroData]) -> 'Batch':
+        assert len(data_list) > 0
+        first = data_list[0]
+        out = cls(num_graphs=len(data_list))
+        node_counts: Dict[str, List[int]] = {}
+        for ntype in first.node_types:
+            counts = [int(d[ntype]['num_nodes']) for d in data_list]
+            node_counts[ntype] = counts
+            store: Dict[str, Any] = {}
+            for name, value in first[ntype].items():
+                if name == 'num_nodes':
+                    store[name] = sum(counts)
+                elif name in _PER_GRAPH_KEYS:
+                    store[name] = torch.tensor([int(d[ntype][name]) for d in data_list], dtype=torch.long)
+                elif torch.is_tensor(value):
+                    store[name] = torch.cat([d[ntype][name] for d in data_list], dim=0)
+                elif isinstance(value, list):
+                    store[name] = [d[ntype][name] for d in data_list]
+                else:
+                    store[name] = [d[ntype][name] for d in data_list]
+            store['batch'] = torch.repeat_interleave(torch.arange(len(data_list), dtype=torch.long),
+                                                     torch.tensor(counts, dtype=torch.long))
+            ptr = torch.zeros(len(data_list) + 1, dtype=torch.long)
+            ptr[1:] = torch.tensor(counts, dtype=torch.long).cumsum(0)
+            store['ptr'] = ptr
+            out[ntype] = store
+        for etype in first.edge_types:
+            src, _, dst = etype
+            src_off = [0]
+            dst_off = [0]
+            for c in node_counts[src][:-1]:
+                src_off.append(src_off[-1] + c)
+            for c in node_counts[dst][:-1]:
+                dst_off.append(dst_off[-1] + c)
+            store = {}
+            for name, value in first[etype].items():
+                if name == 'edge_index':
+                    parts = []
+                    for d, so, do in zip(data_list, src_off, dst_off):
+                        ei = d[etype]['edge_index']
+                        parts.append(ei + ei.new_tensor([[so], [do]]))
+                    store[name] = torch.cat(parts, dim=1)
+                elif torch.is_tensor(value):
+                    store[name] = torch.cat([d[etype][name] for d in data_list], dim=0)
+                else:
+                    store[name] = [d[etype][name] for d in data_list]
+            out[etype] = store
+        for key in first.keys():
+            if key not in out._stores:  # global attributes (scenario_id, city, ...)
+                out[key] = [d[key] for d in data_list]
+        return out

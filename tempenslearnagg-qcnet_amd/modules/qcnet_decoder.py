@@ -1,0 +1,202 @@
+"""QCNetDecoder — drop-in for modules/qcnet_decoder.py:35-294 (same ctor kwargs,
+forward(data, scene_enc, time_shift), output dict and state_dict keys; ``output_head=False`` branch).
+
+The propose/refine stacks run on destination-sorted CSR graphs built once per call.  The K-fold tiling of the
+polygon and agent features (reference :150-151) is folded away: sources are gathered from the single copy.
+``TemporalAggregate`` shares this implementation through the ``_fuse_modes`` hook.
+"""
+from typing import Dict, List, Mapping, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..layers import AttentionLayer, FourierEmbedding, MLPLayer
+from ..utils.graph import CSRGraph, bipartite_dense_to_sparse, dense_to_sparse
+from ..utils.weight_init import weight_init
+from ._common import node_ptr, rel_geometry
+
+
+class QCNetDecoder(nn.Module):
+
+    def __init__(self,
+                 dataset: str,
+                 input_dim: int,
+                 hidden_dim: int,
+                 output_dim: int,
+                 output_head: bool,
+                 num_historical_steps: int,
+                 num_future_steps: int,
+                 num_modes: int,
+                 num_recurrent_steps: int,
+                 num_t2m_steps: Optional[int],
+                 pl2m_radius: float,
+                 a2m_radius: float,
+                 num_freq_bands: int,
+                 num_layers: int,
+                 num_heads: int,
+                 head_dim: int,
+                 dropout: float) -> None:
+        super().__init__()
+        if output_head:
+            raise NotImplementedError('output_head=True (heading outputs) is outside the AV2 configuration')
+        if (num_future_steps * output_dim) % num_recurrent_steps != 0:
+            raise ValueError('num_future_steps * output_dim must be divisible by num_recurrent_steps')
+        self.dataset = dataset
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.output_dim = output_dim
+        self.output_head = output_head
+        self.num_historical_steps = num_historical_steps
+        self.num_future_steps = num_future_steps
+        self.num_modes = num_modes
+        self.num_recurrent_steps = num_recurrent_steps
+        self.num_t2m_steps = num_t2m_steps if num_t2m_steps is not None else num_historical_steps
+        self.pl2m_radius = pl2m_radius
+        self.a2m_radius = a2m_radius
+        self.num_freq_bands = num_freq_bands
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.head_dim = head_dim
+        self.dropout = dropout
+
+        self.mode_emb = nn.Embedding(num_modes, hidden_dim)
+        for name, dim in (('r_t2m_emb', 4), ('r_pl2m_emb', 3), ('r_a2m_emb', 3), ('y_emb', output_dim + output_head)):
+            setattr(self, name, FourierEmbedding(input_dim=dim, hidden_dim=hidden_dim, num_freq_bands=num_freq_bands))
+        self.traj_emb = nn.GRU(input_size=hidden_dim, hidden_size=hidden_dim, num_layers=1, bias=True,
+                               batch_first=False, dropout=0.0, bidirectional=False)
+        self.traj_emb_h0 = nn.Parameter(torch.zeros(1, hidden_dim))
+        layer = dict(hidden_dim=hidden_dim, num_heads=num_heads, head_dim=head_dim, dropout=dropout)
+        for stage in ('propose', 'refine'):
+            for rel in ('t2m', 'pl2m', 'a2m'):
+                setattr(self, '%s_%s_attn_layers' % (rel, stage), nn.ModuleList(
+                    [AttentionLayer(bipartite=True, has_pos_emb=True, **layer) for _ in range(num_layers)]))
+            setattr(self, 'm2m_%s_attn_layer' % stage, AttentionLayer(bipartite=False, has_pos_emb=False, **layer))
+        step_dim = num_future_steps * output_dim // num_recurrent_steps
+        self.to_loc_propose_pos = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=step_dim)
+        self.to_scale_propose_pos = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=step_dim)
+        self.to_loc_refine_pos = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim,
+                                          output_dim=num_future_steps * output_dim)
+        self.to_scale_refine_pos = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim,
+                                            output_dim=num_future_steps * output_dim)
+        self.to_loc_propose_head = None
+        self.to_conc_propose_head = None
+        self.to_loc_refine_head = None
+        self.to_conc_refine_head = None
+        self.to_pi = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=1)
+        self.apply(weight_init)
+
+    # hook: TemporalAggregate sums the stored mode queries of the earlier frames into the new ones here
+    def _fuse_modes(self, m: torch.Tensor, temporal_m: Optional[torch.Tensor]) -> torch.Tensor:
+        return m
+
+    _mode_key = 'm'
+
+    def _cross_stack(self, stage: str, m: torch.Tensor, x_t, x_pl, x_a, r_t2m, r_pl2m, r_a2m,
+                     g_t2m, g_pl2m, g_a2m, g_m2m) -> torch.Tensor:
+        K, C = self.num_modes, self.hidden_dim
+        t2m = getattr(self, 't2m_%s_attn_layers' % stage)
+        pl2m = getattr(self, 'pl2m_%s_attn_layers' % stage)
+        a2m = getattr(self, 'a2m_%s_attn_layers' % stage)
+        for i in range(self.num_layers):
+            m = m.reshape(-1, C)
+            m = t2m[i]((x_t, m), r_t2m, g_t2m)
+            m = m.reshape(-1, K, C).transpose(0, 1).reshape(-1, C)          # agent-major -> mode-major
+            m = pl2m[i]((x_pl, m), r_pl2m, g_pl2m)
+            m = a2m[i]((x_a, m), r_a2m, g_a2m)
+            m = m.reshape(K, -1, C).transpose(0, 1).reshape(-1, C)          # back to agent-major
+        m = getattr(self, 'm2m_%s_attn_layer' % stage)(m, None, g_m2m)
+        return m.reshape(-1, K, C)
+
+    def _decode(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int,
+                temporal_m: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        T, C, K, ts = self.num_historical_steps, self.hidden_dim, self.num_modes, int(time_shift)
+        Tf, OD = self.num_future_steps, self.output_dim
+        agent = data['agent']
+        A = int(agent['num_nodes'])
+        P = int(data['map_polygon']['num_nodes'])
+        pos_m = agent['position'][:, T - 1 + ts, :2].contiguous()
+        head_m = agent['heading'][:, T - 1 + ts].contiguous()
+        dev = pos_m.device
+
+        x_t = scene_enc['x_a'].reshape(-1, C)
+        x_pl = scene_enc['x_pl'][:, T - 1]          # [P, C]; reference tiles it K times (:150)
+        x_a = scene_enc['x_a'][:, -1]               # [A, C]; reference tiles it K times (:151)
+        m = self.mode_emb.weight.repeat(A, 1)
+
+        mask_src = agent['valid_mask'][:, ts:T + ts].clone()
+        mask_src[:, :T - self.num_t2m_steps] = False
+        mask_dst = agent['predict_mask'].any(dim=-1, keepdim=True).repeat(1, K)
+
+        pos_t = agent['position'][:, ts:T + ts, :2].reshape(-1, 2)
+        head_t = agent['heading'][:, ts:T + ts].reshape(-1)
+        ei_t2m_1 = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst[:, -1:].unsqueeze(1))
+        r_t2m = rel_geometry(pos_t, pos_m, head_t, head_m, ei_t2m_1, extra=(ei_t2m_1[0] % T) - T + 1)
+        r_t2m = self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None)
+        ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
+        r_t2m = r_t2m.repeat_interleave(repeats=K, dim=0)
+        g_t2m = CSRGraph.from_edge_index(ei_t2m, A * T, A * K, validate=False)
+
+        pos_pl = data['map_polygon']['position'][:, :2].contiguous()
+        orient_pl = data['map_polygon']['orientation'].contiguous()
+        ptr_a, ptr_p = node_ptr(data, 'agent', dev), node_ptr(data, 'map_polygon', dev)
+        dst_ok = mask_dst[:, 0].contiguous()
+        ei_pl2m_1, _ = ops.radius_pairs(pos_m, pos_pl, self.pl2m_radius, ptr_a, ptr_p, 300, mask_x=dst_ok)
+        r_pl2m = self.r_pl2m_emb(continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1),
+                                 categorical_embs=None)
+        ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
+        r_pl2m = r_pl2m.repeat(K, 1)
+        g_pl2m = CSRGraph.from_edge_index(ei_pl2m, K * P, K * A, validate=False).fold_sources(P)
+
+        src_ok = mask_src[:, -1].contiguous()
+        ei_a2m_1, _ = ops.radius_pairs(pos_m, pos_m, self.a2m_radius, ptr_a, ptr_a, 300 + 1, drop_self=True,
+                                       mask_x=src_ok, mask_y=dst_ok, y_first=False)
+        r_a2m = self.r_a2m_emb(continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1),
+                               categorical_embs=None)
+        ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
+        r_a2m = r_a2m.repeat(K, 1)
+        g_a2m = CSRGraph.from_edge_index(ei_a2m, K * A, K * A, validate=False).fold_sources(A)
+
+        ei_m2m = dense_to_sparse(mask_dst.unsqueeze(2) & mask_dst.unsqueeze(1))[0]
+        g_m2m = CSRGraph.from_edge_index(ei_m2m, A * K, A * K, validate=False)
+
+        graphs = (x_t, x_pl, x_a, r_t2m, r_pl2m, r_a2m, g_t2m, g_pl2m, g_a2m, g_m2m)
+        locs: List[torch.Tensor] = []
+        scales: List[torch.Tensor] = []
+        for _ in range(self.num_recurrent_steps):
+            m = self._cross_stack('propose', m, *graphs)
+            locs.append(self.to_loc_propose_pos(m))
+            scales.append(self.to_scale_propose_pos(m))
+        loc_propose_pos = torch.cumsum(torch.cat(locs, dim=-1).view(-1, K, Tf, OD), dim=-2)
+        scale_propose_pos = torch.cumsum(F.elu(torch.cat(scales, dim=-1).view(-1, K, Tf, OD), alpha=1.0) + 1.0,
+                                         dim=-2) + 0.1
+        loc_propose_head = loc_propose_pos.new_zeros((A, K, Tf, 1))
+        conc_propose_head = scale_propose_pos.new_zeros((A, K, Tf, 1))
+
+        m = self.y_emb(loc_propose_pos.detach().reshape(-1, OD))
+        m = m.reshape(-1, Tf, C).transpose(0, 1)
+        m = self.traj_emb(m, self.traj_emb_h0.unsqueeze(1).repeat(1, m.size(1), 1))[1].squeeze(0)
+        m = self._fuse_modes(m, temporal_m)
+        m = self._cross_stack('refine', m, *graphs)
+
+        loc_refine_pos = self.to_loc_refine_pos(m).view(-1, K, Tf, OD) + loc_propose_pos.detach()
+        scale_refine_pos = F.elu(self.to_scale_refine_pos(m).view(-1, K, Tf, OD), alpha=1.0) + 1.0 + 0.1
+        pi = self.to_pi(m).squeeze(-1)
+        return {
+            'loc_propose_pos': loc_propose_pos,
+            'scale_propose_pos': scale_propose_pos,
+            'loc_propose_head': loc_propose_head,
+            'conc_propose_head': conc_propose_head,
+            'loc_refine_pos': loc_refine_pos,
+            'scale_refine_pos': scale_refine_pos,
+            'loc_refine_head': loc_refine_pos.new_zeros((A, K, Tf, 1)),
+            'conc_refine_head': scale_refine_pos.new_zeros((A, K, Tf, 1)),
+            'pi': pi,
+            self._mode_key: m,
+            'edge_index_pl2m_clone': ei_pl2m_1,
+            'edge_index_t2m': ei_t2m, 'edge_index_pl2m': ei_pl2m, 'edge_index_a2m': ei_a2m, 'edge_index_m2m': ei_m2m,
+        }
+
+    def forward(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int) -> Dict[str, torch.Tensor]:
+        return self._decode(data, scene_enc, time_shift, None)

@@ -1,0 +1,93 @@
+"""QCNetMapEncoder — drop-in for modules/qcnet_map_encoder.py:30-173 (same ctor kwargs, forward(data) and
+state_dict keys; ``input_dim == 2`` / ``argoverse_v2`` branch).
+
+Differences that do not change results: the polygon-to-polygon radius graph comes from the HIP radius kernel;
+both relations are turned into destination-sorted CSR once; ``x_pl`` is returned as a stride-0 [P, T, C] view
+of the [P, C] encoding instead of T materialised copies (reference :170-171).
+"""
+from typing import Dict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..layers import AttentionLayer, FourierEmbedding
+from ..utils.graph import CSRGraph, merge_edges
+from ..utils.weight_init import weight_init
+from ._common import node_ptr, rel_geometry
+
+
+class QCNetMapEncoder(nn.Module):
+
+    def __init__(self,
+                 dataset: str,
+                 input_dim: int,
+                 hidden_dim: int,
+                 num_historical_steps: int,
+                 pl2pl_radius: float,
+                 num_freq_bands: int,
+                 num_layers: int,
+                 num_heads: int,
+                 head_dim: int,
+                 dropout: float) -> None:
+        super().__init__()
+        if dataset != 'argoverse_v2':
+            raise ValueError('{} is not a valid dataset'.format(dataset))
+        if input_dim != 2:
+            raise NotImplementedError('only the 2-D AV2 configuration (input_dim=2) is implemented')
+        self.dataset = dataset
+        self.input_dim = input_dim
+        self.hidden_dim = hidden_dim
+        self.num_historical_steps = num_historical_steps
+        self.pl2pl_radius = pl2pl_radius
+        self.num_freq_bands = num_freq_bands
+        self.num_layers = num_layers
+        self.num_heads = num_heads
+        self.head_dim = head_dim
+        self.dropout = dropout
+
+        for name, vocab in (('type_pt_emb', 17), ('side_pt_emb', 3), ('type_pl_emb', 4), ('int_pl_emb', 3),
+                            ('type_pl2pl_emb', 5)):
+            setattr(self, name, nn.Embedding(vocab, hidden_dim))
+        for name, dim in (('x_pt_emb', 1), ('x_pl_emb', 0), ('r_pt2pl_emb', 3), ('r_pl2pl_emb', 3)):
+            setattr(self, name, FourierEmbedding(input_dim=dim, hidden_dim=hidden_dim, num_freq_bands=num_freq_bands))
+        layer = dict(hidden_dim=hidden_dim, num_heads=num_heads, head_dim=head_dim, dropout=dropout, has_pos_emb=True)
+        self.pt2pl_layers = nn.ModuleList([AttentionLayer(bipartite=True, **layer) for _ in range(num_layers)])
+        self.pl2pl_layers = nn.ModuleList([AttentionLayer(bipartite=False, **layer) for _ in range(num_layers)])
+        self.apply(weight_init)
+
+    def forward(self, data) -> Dict[str, torch.Tensor]:
+        pt, pl = data['map_point'], data['map_polygon']
+        pos_pt = pt['position'][:, :2].contiguous()
+        orient_pt = pt['orientation'].contiguous()
+        pos_pl = pl['position'][:, :2].contiguous()
+        orient_pl = pl['orientation'].contiguous()
+        n_pt, n_pl = pos_pt.size(0), pos_pl.size(0)
+
+        x_pt = self.x_pt_emb(continuous_inputs=pt['magnitude'].unsqueeze(-1),
+                             categorical_embs=[self.type_pt_emb(pt['type'].long()), self.side_pt_emb(pt['side'].long())])
+        x_pl = self.x_pl_emb(continuous_inputs=None,
+                             categorical_embs=[self.type_pl_emb(pl['type'].long()),
+                                               self.int_pl_emb(pl['is_intersection'].long())])
+
+        ei_pt2pl = data['map_point', 'to', 'map_polygon']['edge_index']
+        g_pt2pl = CSRGraph.from_edge_index(ei_pt2pl, n_pt, n_pl)
+        r_pt2pl = self.r_pt2pl_emb(continuous_inputs=rel_geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl),
+                                   categorical_embs=None)
+
+        ptr_pl = node_ptr(data, 'map_polygon', pos_pl.device)
+        ei_radius, _ = ops.radius_pairs(pos_pl, pos_pl, self.pl2pl_radius, ptr_pl, ptr_pl, 300 + 1, drop_self=True,
+                                        y_first=False)
+        type_data = data['map_polygon', 'to', 'map_polygon']['type']
+        ei_pl2pl, type_pl2pl = merge_edges(
+            edge_indices=[ei_radius, data['map_polygon', 'to', 'map_polygon']['edge_index']],
+            edge_attrs=[type_data.new_zeros(ei_radius.size(1), dtype=torch.uint8), type_data], reduce='max')
+        g_pl2pl = CSRGraph.from_edge_index(ei_pl2pl, n_pl, n_pl)
+        r_pl2pl = self.r_pl2pl_emb(continuous_inputs=rel_geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl),
+                                   categorical_embs=[self.type_pl2pl_emb(type_pl2pl.long())])
+
+        for i in range(self.num_layers):
+            x_pl = self.pt2pl_layers[i]((x_pt, x_pl), r_pt2pl, g_pt2pl)
+            x_pl = self.pl2pl_layers[i](x_pl, r_pl2pl, g_pl2pl)
+        x_pl = x_pl.unsqueeze(1).expand(-1, self.num_historical_steps, -1)
+        return {'x_pt': x_pt, 'x_pl': x_pl, 'edge_index_pl2pl': ei_pl2pl, 'type_pl2pl': type_pl2pl}

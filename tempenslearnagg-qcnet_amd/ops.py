@@ -1,0 +1,150 @@
+"""Tensor-level wrappers over the C ABI (include/qcnet_hip.h).
+
+Each wrapper validates shapes / dtypes / devices on the host before a kernel sees a pointer (a kernel that
+faults can take the whole GPU host down), allocates outputs and workspaces with torch (plumbing only) and
+launches on torch's current stream.  No wrapper has a CPU or eager fallback.
+"""
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+C = 128  # QCN_CHANNELS
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device: torch.device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _require(t: torch.Tensor, name: str, dtype: torch.dtype, device: torch.device, shape=None) -> None:
+    if not torch.is_tensor(t):
+        raise TypeError('%s must be a tensor' % name)
+    if not t.is_cuda:
+        raise _lib.QcnError('%s is on %s: the QCNet hot path runs on the GPU only (no CPU fallback)' % (name, t.device))
+    if t.device != device:
+        raise ValueError('%s is on %s, expected %s' % (name, t.device, device))
+    if t.dtype != dtype:
+        raise TypeError('%s has dtype %s, expected %s' % (name, t.dtype, dtype))
+    if not t.is_contiguous():
+        raise ValueError('%s must be contiguous' % name)
+    if shape is not None:
+        if t.dim() != len(shape) or any(s is not None and int(d) != int(s) for d, s in zip(t.shape, shape)):
+            raise ValueError('%s has shape %s, expected %s' % (name, tuple(t.shape), tuple(shape)))
+
+
+# ------------------------------------------------------------------------------------------------
+# radius search
+# ------------------------------------------------------------------------------------------------
+def radius_pairs(x: torch.Tensor, y: torch.Tensor, r: float, ptr_x: torch.Tensor, ptr_y: torch.Tensor,
+                 max_num_neighbors: int, drop_self: bool = False, mask_x: Optional[torch.Tensor] = None,
+                 mask_y: Optional[torch.Tensor] = None, y_first: bool = True
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """All (y, x) pairs of the same example with ||x - y||^2 < r^2 (qcn_radius_count / _fill).
+
+    Returns ``(edge_index [2, E] int64, offset [n_y + 1] int64)``; ``edge_index`` rows are (y, x) when
+    ``y_first`` else (x, y); pairs are grouped by ascending y, ``offset`` is the CSR row pointer over y.
+    Costs one host synchronisation (E must be known to allocate the output).
+    """
+    dev = x.device
+    dim = x.size(1) if x.dim() == 2 else -1
+    _require(x, 'x', torch.float32, dev, (None, dim))
+    _require(y, 'y', torch.float32, dev, (None, dim))
+    if dim not in (2, 3):
+        raise _lib.QcnError('radius search supports 2-D or 3-D points, got dim=%d' % dim)
+    num_examples = ptr_x.numel() - 1
+    _require(ptr_x, 'ptr_x', torch.int64, dev, (num_examples + 1,))
+    _require(ptr_y, 'ptr_y', torch.int64, dev, (num_examples + 1,))
+    n_x, n_y = x.size(0), y.size(0)
+    mx = my = None
+    if mask_x is not None:
+        mx = mask_x.view(torch.uint8) if mask_x.dtype == torch.bool else mask_x
+        _require(mx, 'mask_x', torch.uint8, dev, (n_x,))
+    if mask_y is not None:
+        my = mask_y.view(torch.uint8) if mask_y.dtype == torch.bool else mask_y
+        _require(my, 'mask_y', torch.uint8, dev, (n_y,))
+    if drop_self and n_x != n_y:
+        raise ValueError('drop_self needs x and y to be the same point set')
+    r2 = float(torch.tensor(float(r) * float(r), dtype=torch.float64).float())  # (scalar_t)(r * r), as upstream
+    lib = _lib.lib()
+    st = _stream(dev)
+    count = torch.zeros(n_y + 1, dtype=torch.int32, device=dev)
+    offset = torch.empty(n_y + 1, dtype=torch.int64, device=dev)
+    common = (_ptr(x), _ptr(y), _ptr(ptr_x), _ptr(ptr_y), num_examples, n_y, dim, r2, int(max_num_neighbors),
+              int(bool(drop_self)), _ptr(mx), _ptr(my))
+    _lib.check(lib.qcn_radius_count(*common, _ptr(count), st), 'qcn_radius_count')
+    ws_bytes = lib.qcn_scan_workspace_bytes(n_y)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.qcn_exclusive_scan_i32(_ptr(count), n_y, _ptr(offset), _ptr(ws), ws_bytes, st),
+               'qcn_exclusive_scan_i32')
+    num_edges = int(offset[-1].item())
+    edge_index = torch.empty(2, num_edges, dtype=torch.int64, device=dev)
+    if num_edges > 0:
+        row, col = (edge_index[0], edge_index[1]) if y_first else (edge_index[1], edge_index[0])
+        _lib.check(lib.qcn_radius_fill(*common, _ptr(offset), _ptr(row), _ptr(col), st), 'qcn_radius_fill')
+    return edge_index, offset
+
+
+# ------------------------------------------------------------------------------------------------
+# CSR
+# ------------------------------------------------------------------------------------------------
+def csr_build(edge_index: torch.Tensor, n_dst: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Stable destination sort of a COO edge list → (rowptr int32 [n_dst+1], col int32 [E], eid int32 [E])."""
+    dev = edge_index.device
+    _require(edge_index, 'edge_index', torch.int64, dev, (2, None))
+    num_edges = edge_index.size(1)
+    rowptr = torch.empty(n_dst + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(num_edges, dtype=torch.int32, device=dev)
+    eid = torch.empty(num_edges, dtype=torch.int32, device=dev)
+    lib = _lib.lib()
+    ws_bytes = lib.qcn_csr_workspace_bytes(num_edges, n_dst)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.qcn_csr_build(_ptr(edge_index[0]), _ptr(edge_index[1]), num_edges, n_dst, _ptr(rowptr), _ptr(col),
+                                 _ptr(eid), _ptr(ws), ws_bytes, _stream(dev)), 'qcn_csr_build')
+    return rowptr, col, eid
+
+
+# ------------------------------------------------------------------------------------------------
+# attention propagate
+# ------------------------------------------------------------------------------------------------
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kr: Optional[torch.Tensor],
+             vr: Optional[torch.Tensor], rowptr: torch.Tensor, col: torch.Tensor,
+             eid: Optional[torch.Tensor]) -> torch.Tensor:
+    """qcn_attn_fwd_f32: gather + segment softmax + weighted scatter-add, [n_dst, 128] fp32."""
+    dev = q.device
+    n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
+    _require(q, 'q', torch.float32, dev, (n_dst, C))
+    _require(k, 'k', torch.float32, dev, (n_src, C))
+    _require(v, 'v', torch.float32, dev, (n_src, C))
+    _require(rowptr, 'rowptr', torch.int32, dev, (n_dst + 1,))
+    _require(col, 'col', torch.int32, dev, (num_edges,))
+    if (kr is None) != (vr is None):
+        raise ValueError('kr and vr must be given together')
+    if kr is not None:
+        _require(kr, 'kr', torch.float32, dev, (num_edges, C))
+        _require(vr, 'vr', torch.float32, dev, (num_edges, C))
+    if eid is not None:
+        _require(eid, 'eid', torch.int32, dev, (num_edges,))
+    out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_attn_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(kr), _ptr(vr), _ptr(rowptr), _ptr(col),
+                                           _ptr(eid), n_dst, n_src, num_edges, _ptr(out), _stream(dev)),
+               'qcn_attn_fwd_f32')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# profiling hooks for bench.py
+# ------------------------------------------------------------------------------------------------
+def prof_enable(on: bool) -> None:
+    _lib.check(_lib.lib().qcn_prof_enable(int(bool(on))), 'qcn_prof_enable')
+
+
+def prof_collect() -> Tuple[int, float, float]:
+    n, ms, b = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
+    _lib.check(_lib.lib().qcn_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)), 'qcn_prof_collect')
+    return int(n.value), float(ms.value), float(b.value)

@@ -1,0 +1,60 @@
+"""TempEnsLearnAgg — inference counterpart of predictors/temp_ens_learn_agg.py:22-282.
+
+Keeps the sub-module names ``base_model`` (a frozen QCNetSliding, reference :26) and
+``temporal_aggregate_layer`` (a TemporalAggregate initialised from the base decoder's weights, :61-81),
+``forward(data, time_shift)`` (:123-126) and the frame loop of ``validation_step`` (:196-221) as ``predict``.
+Training (losses, optimiser, Lightning hooks) and checkpoint download are outside the hot path: the model is
+built from explicit hyper-parameters instead of ``load_from_checkpoint``.
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..modules import TemporalAggregate
+from .qcnet_sliding import QCNetSliding
+
+
+class TempEnsLearnAgg(nn.Module):
+
+    num_frames = 10  # time_shift = 1..10, reference :197
+
+    def __init__(self, base_model: Optional[QCNetSliding] = None, share_map_encoding: bool = True, **hparams) -> None:
+        super().__init__()
+        self.base_model = base_model if base_model is not None else QCNetSliding(**hparams)
+        hp = self.base_model.hparams
+        for key, value in hp.items():
+            setattr(self, key, value)
+        self.temporal_aggregate_layer = TemporalAggregate(
+            dataset=hp['dataset'], input_dim=hp['input_dim'], hidden_dim=hp['hidden_dim'], output_dim=hp['output_dim'],
+            output_head=hp['output_head'], num_historical_steps=hp['num_historical_steps'],
+            num_future_steps=hp['num_future_steps'], num_modes=hp['num_modes'],
+            num_recurrent_steps=hp['num_recurrent_steps'], num_t2m_steps=hp['num_t2m_steps'],
+            pl2m_radius=hp['pl2m_radius'], a2m_radius=hp['a2m_radius'], num_freq_bands=hp['num_freq_bands'],
+            num_layers=hp['num_dec_layers'], num_heads=hp['num_heads'], head_dim=hp['head_dim'], dropout=hp['dropout'])
+        self.temporal_aggregate_layer.load_state_dict(self.base_model.decoder.state_dict())
+        # The map encoder does not depend on time_shift; the reference recomputes it for every frame.
+        self.share_map_encoding = share_map_encoding
+
+    def forward(self, data, time_shift: int, map_enc=None) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+        scene_enc = self.base_model.encoder(data, time_shift, map_enc=map_enc)
+        pred = self.base_model.decoder(data, scene_enc, time_shift)
+        return pred, scene_enc
+
+    @torch.no_grad()
+    def predict(self, data) -> Dict[str, torch.Tensor]:
+        """Ten sliding QCNet frames + learned aggregation (reference :196-221, :261)."""
+        map_enc = self.base_model.encoder.map_encoder(data) if self.share_map_encoding else None
+        temporal_m = []
+        scene_enc = None
+        for time_shift in range(1, self.num_frames + 1):
+            pred, scene_enc = self(data, time_shift, map_enc=map_enc)
+            temporal_m.append(pred['m'])
+        temporal_m = torch.stack(temporal_m, dim=1)
+        pred = self.temporal_aggregate_layer(temporal_m, data, scene_enc, self.num_frames)
+        traj_refine = torch.cat([pred['loc_refine_pos'][..., :self.output_dim],
+                                 pred['scale_refine_pos'][..., :self.output_dim]], dim=-1)
+        pred['traj_refine'] = traj_refine[..., :50, :]
+        pred['pi_softmax'] = F.softmax(pred['pi'], dim=-1)
+        return pred

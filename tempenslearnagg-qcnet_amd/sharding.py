@@ -1,0 +1,93 @@
+"""Scenario sharding across the GPUs of one node.
+
+Scenarios are independent units (no relation crosses a scenario: every graph is built per example), so the path
+shards with no collective inside the forward.  Each rank takes scenario ids ``rank, rank + W, ...``, runs them in
+batches, and the only exchanges are one ``all_gather`` of fixed-size per-scenario prediction records and one
+``all_reduce(sum)`` of metric ``(sum, count)`` pairs — the counterparts of Lightning's ``sync_dist`` logging and the
+torchmetrics ``dist_reduce_fx='sum'`` states of the reference (predictors/temp_ens_learn_agg.py:243-247,
+metrics/min_ade.py:29-30).  Backend: ``nccl`` (= RCCL over xGMI) on GPUs, ``gloo`` in the CPU tests.
+"""
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+RECORD_MODES = 6
+RECORD_STEPS = 50
+RECORD_WIDTH = 1 + RECORD_MODES * RECORD_STEPS * 2 + RECORD_MODES   # scenario id, trajectories, probabilities
+
+
+def shard_scenario_ids(num_scenarios: int, rank: int, world_size: int) -> List[int]:
+    return list(range(rank, num_scenarios, world_size))
+
+
+def batches(ids: Sequence[int], batch_size: int) -> List[List[int]]:
+    return [list(ids[i:i + batch_size]) for i in range(0, len(ids), batch_size)]
+
+
+def focal_records(scenario_ids: Sequence[int], data, pred: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """One fp32 record per scenario: [scenario id, traj_refine[focal, :, :50, :2] (agent frame), softmax(pi)]."""
+    focal = (data['agent']['category'] == 3).nonzero(as_tuple=True)[0]
+    assert focal.numel() == len(scenario_ids), 'expected exactly one focal track per scenario'
+    traj = pred['traj_refine'][focal][..., :2].reshape(len(scenario_ids), -1)
+    prob = pred['pi_softmax'][focal]
+    ids = torch.tensor(list(scenario_ids), dtype=torch.float32, device=traj.device).unsqueeze(1)
+    return torch.cat([ids, traj.float(), prob.float()], dim=1)
+
+
+def endpoint_metric_sums(data, pred: Dict[str, torch.Tensor], time_shift: int = 10) -> torch.Tensor:
+    """(sum, count) pairs of minADE / minFDE / miss-rate (2 m) of the focal tracks against the synthetic future,
+    in the agent frame of step 49 + time_shift (ground truth as predictors/temp_ens_learn_agg.py:104-121)."""
+    T = 50
+    agent = data['agent']
+    focal = (agent['category'] == 3).nonzero(as_tuple=True)[0]
+    origin = agent['position'][focal, T - 1 + time_shift, :2]
+    theta = agent['heading'][focal, T - 1 + time_shift]
+    cos, sin = theta.cos(), theta.sin()
+    rot = torch.stack([torch.stack([cos, -sin], dim=-1), torch.stack([sin, cos], dim=-1)], dim=-2)
+    gt = torch.bmm(agent['position'][focal, T + time_shift:, :2] - origin.unsqueeze(1), rot)      # [F, 50, 2]
+    valid = agent['predict_mask'][focal, T + time_shift:].float()
+    traj = pred['traj_refine'][focal][..., :2]                                                     # [F, K, 50, 2]
+    dist_ = torch.norm(traj - gt.unsqueeze(1), p=2, dim=-1) * valid.unsqueeze(1)
+    ade = (dist_.sum(-1) / valid.sum(-1, keepdim=True).clamp(min=1)).min(dim=1).values
+    fde = dist_[..., -1].min(dim=1).values
+    n = torch.tensor(float(focal.numel()), device=traj.device)
+    return torch.stack([ade.sum(), n, fde.sum(), n, (fde > 2.0).float().sum(), n])
+
+
+def gather_records(records: torch.Tensor, world_size: int) -> torch.Tensor:
+    """all_gather of per-scenario records from every rank (ragged counts padded to the max), sorted by id."""
+    if world_size == 1 or not dist.is_initialized():
+        out = records
+    else:
+        count = torch.tensor([records.size(0)], dtype=torch.int64, device=records.device)
+        counts = [torch.zeros_like(count) for _ in range(world_size)]
+        dist.all_gather(counts, count)
+        cap = int(max(int(c) for c in counts))
+        padded = records.new_full((cap, records.size(1)), -1.0)
+        padded[:records.size(0)] = records
+        gathered = records.new_empty((world_size * cap, records.size(1)))
+        dist.all_gather_into_tensor(gathered, padded)
+        keep = torch.cat([torch.arange(cap, device=records.device) < int(c) for c in counts])
+        out = gathered[keep]
+    return out[torch.argsort(out[:, 0])]
+
+
+def reduce_metric_sums(sums: torch.Tensor, world_size: int) -> torch.Tensor:
+    if world_size > 1 and dist.is_initialized():
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums
+
+
+def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], object], num_scenarios: int,
+                batch_size: int, rank: int, world_size: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Runs this rank's shard and returns (all records sorted by scenario id, reduced metric sums)."""
+    records = []
+    sums = torch.zeros(6, device=device)
+    for ids in batches(shard_scenario_ids(num_scenarios, rank, world_size), batch_size):
+        data = make_batch_fn(ids).to(device)
+        pred = predict_fn(data)
+        records.append(focal_records(ids, data, pred))
+        sums += endpoint_metric_sums(data, pred).to(sums.dtype)
+    records = torch.cat(records) if records else torch.empty(0, RECORD_WIDTH, device=device)
+    return gather_records(records, world_size), reduce_metric_sums(sums, world_size)

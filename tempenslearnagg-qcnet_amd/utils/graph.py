@@ -1,0 +1,171 @@
+"""Graph construction for the QCNet path: MI355X-native counterparts of the torch_cluster / torch_geometric
+utilities the reference modules call, with the same signatures and result order.
+
+* ``radius`` / ``radius_graph``  — torch_cluster 1.6.1 signatures (modules/qcnet_agent_encoder.py:158,168);
+  canonical result order of SURVEY.md §8 G1/G2 (y ascending, x ascending inside a y, lowest-index survivors
+  under the neighbour cap).
+* ``dense_to_sparse`` / ``bipartite_dense_to_sparse`` / ``subgraph`` / ``coalesce`` / ``merge_edges`` —
+  torch_geometric 2.3.0 semantics and utils/graph.py:45-54,88-94.
+* ``CSRGraph`` — the destination-sorted CSR every AttentionLayer call consumes.  The reference rebuilds its
+  gather/scatter indexing from COO inside every propagate call; here a relation's CSR is built once and
+  shared by all layers that use the relation.
+"""
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+
+
+class CSRGraph:
+    """A bipartite relation src → dst in two forms: the reference-order COO ``edge_index`` ([2, E] int64)
+    and a destination-sorted CSR (``rowptr`` int32 [n_dst + 1], ``col`` int32 [E] source per slot,
+    ``eid`` int32 [E] original edge id per slot, or None when the COO order already is the CSR order)."""
+
+    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid')
+
+    def __init__(self, edge_index, n_src, n_dst, rowptr, col, eid):
+        self.edge_index = edge_index
+        self.n_src = int(n_src)
+        self.n_dst = int(n_dst)
+        self.rowptr = rowptr
+        self.col = col
+        self.eid = eid
+
+    @property
+    def num_edges(self) -> int:
+        return int(self.col.numel())
+
+    @classmethod
+    def from_edge_index(cls, edge_index: torch.Tensor, n_src: int, n_dst: int, validate: bool = True) -> 'CSRGraph':
+        if edge_index.dim() != 2 or edge_index.size(0) != 2:
+            raise ValueError('edge_index must be [2, E]')
+        edge_index = edge_index.contiguous()
+        if validate and edge_index.size(1) > 0:
+            # One host sync; keeps a malformed edge list from becoming an out-of-bounds gather on the GPU.
+            lo = int(edge_index.min())
+            hi_src, hi_dst = int(edge_index[0].max()), int(edge_index[1].max())
+            if lo < 0 or hi_src >= n_src or hi_dst >= n_dst:
+                raise IndexError('edge_index out of range: min %d, max src %d (n_src %d), max dst %d (n_dst %d)'
+                                 % (lo, hi_src, n_src, hi_dst, n_dst))
+        rowptr, col, eid = ops.csr_build(edge_index, n_dst)
+        return cls(edge_index, n_src, n_dst, rowptr, col, eid)
+
+    def fold_sources(self, period: int) -> 'CSRGraph':
+        """Source rows that are ``period``-periodic copies (the reference tiles ``x_pl`` T times,
+        modules/qcnet_map_encoder.py:170, and K times, modules/qcnet_decoder.py:150-151) are gathered from one
+        copy: source index modulo ``period``.  ``edge_index`` keeps the reference numbering."""
+        return CSRGraph(self.edge_index, period, self.n_dst, self.rowptr, torch.remainder(self.col, period), self.eid)
+
+    @classmethod
+    def from_sorted(cls, edge_index: torch.Tensor, offset: torch.Tensor, n_src: int, n_dst: int) -> 'CSRGraph':
+        """``edge_index`` already grouped by ascending destination with row pointer ``offset`` (int64)."""
+        return cls(edge_index, n_src, n_dst, offset.to(torch.int32), edge_index[0].to(torch.int32), None)
+
+
+def _ptr_from_batch(batch: Optional[torch.Tensor], n: int, device) -> torch.Tensor:
+    if batch is None:
+        return torch.tensor([0, n], dtype=torch.int64, device=device)
+    batch_size = int(batch.max()) + 1 if batch.numel() > 0 else 1
+    return torch.bucketize(torch.arange(batch_size + 1, device=device, dtype=torch.int64), batch)
+
+
+def _align_ptrs(ptr_x: torch.Tensor, ptr_y: torch.Tensor, n_x: int, n_y: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    # batch_size = max over both batch vectors (torch_cluster/radius.py); pad the shorter ptr with its total.
+    if ptr_x.numel() < ptr_y.numel():
+        ptr_x = torch.cat([ptr_x, ptr_x.new_full((ptr_y.numel() - ptr_x.numel(),), n_x)])
+    elif ptr_y.numel() < ptr_x.numel():
+        ptr_y = torch.cat([ptr_y, ptr_y.new_full((ptr_x.numel() - ptr_y.numel(),), n_y)])
+    return ptr_x, ptr_y
+
+
+def radius(x: torch.Tensor, y: torch.Tensor, r: float, batch_x: Optional[torch.Tensor] = None,
+           batch_y: Optional[torch.Tensor] = None, max_num_neighbors: int = 32, num_workers: int = 1) -> torch.Tensor:
+    """Drop-in for ``torch_cluster.radius``: [2, E] int64, row0 = y index, row1 = x index."""
+    if x.numel() == 0 or y.numel() == 0:
+        return torch.empty(2, 0, dtype=torch.long, device=x.device)
+    x = x.reshape(-1, 1) if x.dim() == 1 else x
+    y = y.reshape(-1, 1) if y.dim() == 1 else y
+    x, y = x.contiguous().float(), y.contiguous().float()
+    if (batch_x is None) != (batch_y is None):
+        raise AssertionError('batch_x and batch_y must be given together')
+    ptr_x = _ptr_from_batch(batch_x, x.size(0), x.device)
+    ptr_y = _ptr_from_batch(batch_y, y.size(0), x.device)
+    ptr_x, ptr_y = _align_ptrs(ptr_x, ptr_y, x.size(0), y.size(0))
+    edge_index, _ = ops.radius_pairs(x, y, r, ptr_x, ptr_y, max_num_neighbors)
+    return edge_index
+
+
+def radius_graph(x: torch.Tensor, r: float, batch: Optional[torch.Tensor] = None, loop: bool = False,
+                 max_num_neighbors: int = 32, flow: str = 'source_to_target', num_workers: int = 1) -> torch.Tensor:
+    """Drop-in for ``torch_cluster.radius_graph``: row0 = neighbour (source), row1 = query (target) for
+    ``source_to_target``; the neighbour cap is ``max_num_neighbors + 1`` hits including the self pair."""
+    assert flow in ('source_to_target', 'target_to_source')
+    if x.numel() == 0:
+        return torch.empty(2, 0, dtype=torch.long, device=x.device)
+    x = x.reshape(-1, 1) if x.dim() == 1 else x
+    x = x.contiguous().float()
+    ptr = _ptr_from_batch(batch, x.size(0), x.device)
+    cap = max_num_neighbors if loop else max_num_neighbors + 1
+    edge_index, _ = ops.radius_pairs(x, x, r, ptr, ptr, cap, drop_self=not loop,
+                                     y_first=(flow != 'source_to_target'))
+    return edge_index
+
+
+def dense_to_sparse(adj: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``torch_geometric.utils.dense_to_sparse`` for a [B, n, n] (or [n, n]) adjacency: row-major nonzero
+    order, node ids offset by ``b * n``.  Returns ``(edge_index, edge_attr)`` like PyG."""
+    if adj.dim() == 2:
+        idx = adj.nonzero(as_tuple=True)
+        return torch.stack(idx, dim=0), adj[idx]
+    b, i, j = adj.nonzero(as_tuple=True)
+    return torch.stack([b * adj.size(1) + i, b * adj.size(2) + j], dim=0), adj[b, i, j]
+
+
+def bipartite_dense_to_sparse(adj: torch.Tensor) -> torch.Tensor:
+    """utils/graph.py:88-94 — [B, n, m] mask → src = b*n + i, dst = b*m + j."""
+    idx = adj.nonzero(as_tuple=True)
+    if len(idx) == 3:
+        return torch.stack([idx[0] * adj.size(1) + idx[1], idx[0] * adj.size(2) + idx[2]], dim=0)
+    return torch.stack(idx, dim=0)
+
+
+def subgraph(subset: torch.Tensor, edge_index: torch.Tensor,
+             edge_attr: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """``torch_geometric.utils.subgraph`` with a bool node mask and ``relabel_nodes=False``."""
+    if subset.dtype != torch.bool:
+        mask = torch.zeros(int(edge_index.max()) + 1 if edge_index.numel() else 0, dtype=torch.bool,
+                           device=edge_index.device)
+        mask[subset] = True
+        subset = mask
+    keep = subset[edge_index[0]] & subset[edge_index[1]]
+    return edge_index[:, keep], (edge_attr[keep] if edge_attr is not None else None)
+
+
+def coalesce(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor] = None, num_nodes: Optional[int] = None,
+             reduce: str = 'add') -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """``torch_geometric.utils.coalesce``: sort by (row, col), merge duplicates with ``reduce``."""
+    if edge_index.size(1) == 0:
+        return (edge_index, edge_attr) if edge_attr is not None else edge_index
+    n = int(edge_index.max()) + 1 if num_nodes is None else int(num_nodes)
+    key = edge_index[0] * n + edge_index[1]
+    uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
+    out_index = torch.stack([torch.div(uniq, n, rounding_mode='floor'), uniq % n], dim=0)
+    if edge_attr is None:
+        return out_index
+    torch_reduce = {'add': 'sum', 'sum': 'sum', 'max': 'amax', 'min': 'amin', 'mean': 'mean'}[reduce]
+    work = edge_attr.long() if not edge_attr.is_floating_point() else edge_attr
+    out_attr = work.new_zeros((uniq.numel(),) + tuple(work.shape[1:]))
+    idx = inverse.view(-1, *([1] * (work.dim() - 1))).expand_as(work)
+    out_attr.scatter_reduce_(0, idx, work, reduce=torch_reduce, include_self=False)
+    return out_index, out_attr.to(edge_attr.dtype)
+
+
+def merge_edges(edge_indices: List[torch.Tensor], edge_attrs: Optional[List[torch.Tensor]] = None,
+                reduce: str = 'add') -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """utils/graph.py:45-54."""
+    edge_index = torch.cat(edge_indices, dim=1)
+    edge_attr = torch.cat(edge_attrs, dim=0) if edge_attrs is not None else None
+    if edge_attr is None:
+        return coalesce(edge_index, None, reduce=reduce), None
+    return coalesce(edge_index, edge_attr, reduce=reduce)

@@ -1,0 +1,119 @@
+"""GPU parity: the fused attention kernel and AttentionLayer against the oracle (fp32, 1e-4 relative)."""
+import pytest
+import torch
+
+from helpers import c_attention, cpu_state_dict, oracle, randomize_, rel_err
+
+from tempenslearnagg_qcnet_amd import ops
+from tempenslearnagg_qcnet_amd.layers import AttentionLayer
+from tempenslearnagg_qcnet_amd.utils.graph import CSRGraph
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = 1e-4   # BASELINE.json north_star: fp32 outputs within 1e-4 relative
+
+
+def _graph(n_src, n_dst, E, seed, heavy=None, empty_from=None):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, n_src, (E,), generator=g)
+    hi = n_dst if empty_from is None else empty_from
+    dst = torch.randint(0, hi, (E,), generator=g)
+    if heavy is not None:
+        dst[:heavy] = 3
+    return torch.stack([src, dst])
+
+
+def _feat(n, seed, scale=1.0):
+    return torch.randn(n, 128, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize('n_src,n_dst,E,has_r,heavy,empty_from', [
+    (40, 30, 500, True, None, None),
+    (40, 30, 500, False, None, None),
+    (300, 257, 9000, True, 700, None),       # one destination with 700+ in-edges, n_dst not a multiple of 4
+    (64, 100, 333, True, None, 60),          # destinations 60.. have no edges -> exact zeros
+    (5, 9, 0, True, None, None),             # no edges at all
+    (1, 1, 3, False, None, None),
+])
+def test_attn_kernel_vs_fp64_oracle(n_src, n_dst, E, has_r, heavy, empty_from):
+    ei = _graph(n_src, n_dst, E, 11, heavy, empty_from)
+    q, k, v = _feat(n_dst, 1, 1.5), _feat(n_src, 2, 1.5), _feat(n_src, 3)
+    kr = _feat(E, 4, 0.5) if has_r else None
+    vr = _feat(E, 5, 0.5) if has_r else None
+    want = c_attention(q, k, v, kr, vr, ei)
+    graph = CSRGraph.from_edge_index(ei.to(DEV), n_src, n_dst)
+    got = ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), None if kr is None else kr.to(DEV),
+                       None if vr is None else vr.to(DEV), graph.rowptr, graph.col, graph.eid)
+    torch.cuda.synchronize()
+    assert got.shape == (n_dst, 128)
+    if E:
+        assert rel_err(got, want) < 1e-5
+    deg = torch.bincount(ei[1], minlength=n_dst)
+    assert bool((got.cpu()[deg == 0] == 0).all())
+
+
+def test_attn_kernel_large_logits_and_edge_permutation_invariance():
+    n_src, n_dst, E = 200, 150, 6000
+    ei = _graph(n_src, n_dst, E, 12)
+    q, k, v = _feat(n_dst, 1, 6.0), _feat(n_src, 2, 6.0), _feat(n_src, 3)   # logits of +-100: softmax must not overflow
+    kr, vr = _feat(E, 4), _feat(E, 5)
+    want = c_attention(q, k, v, kr, vr, ei)
+    def run(perm):
+        e = ei[:, perm].to(DEV)
+        g = CSRGraph.from_edge_index(e, n_src, n_dst)
+        return ops.attn_fwd(q.to(DEV), k.to(DEV), v.to(DEV), kr[perm].to(DEV), vr[perm].to(DEV), g.rowptr, g.col, g.eid)
+    a = run(torch.arange(E))
+    b = run(torch.randperm(E, generator=torch.Generator().manual_seed(1)))
+    assert torch.isfinite(a).all()
+    assert rel_err(a, want) < 1e-5 and rel_err(b, want) < 1e-5
+
+
+def test_attn_wrapper_rejects_bad_inputs():
+    ei = _graph(10, 10, 50, 13).to(DEV)
+    g = CSRGraph.from_edge_index(ei, 10, 10)
+    q = torch.randn(10, 128, device=DEV)
+    with pytest.raises(Exception):
+        ops.attn_fwd(q.cpu(), q, q, None, None, g.rowptr, g.col, g.eid)           # CPU tensor: no fallback
+    with pytest.raises(ValueError):
+        ops.attn_fwd(q[:, :64].contiguous(), q, q, None, None, g.rowptr, g.col, g.eid)
+    with pytest.raises(ValueError):
+        ops.attn_fwd(q, q, q, torch.randn(49, 128, device=DEV), torch.randn(49, 128, device=DEV), g.rowptr, g.col, g.eid)
+    with pytest.raises(IndexError):
+        CSRGraph.from_edge_index(ei + 5, 10, 10)
+
+
+@pytest.mark.parametrize('bipartite,has_pos_emb', [(True, True), (False, True), (False, False)])
+def test_attention_layer_vs_oracle(bipartite, has_pos_emb):
+    torch.manual_seed(3)
+    layer = randomize_(AttentionLayer(hidden_dim=128, num_heads=8, head_dim=16, dropout=0.1, bipartite=bipartite,
+                                      has_pos_emb=has_pos_emb), seed=5).eval()
+    sd = cpu_state_dict(layer)
+    n_src, n_dst, E = (90, 70, 2500) if bipartite else (80, 80, 2500)
+    ei = _graph(n_src, n_dst, E, 21, heavy=300, empty_from=n_dst - 7)
+    x_src, x_dst = _feat(n_src, 6), _feat(n_dst, 7)
+    r = _feat(E, 8) if has_pos_emb else None
+    x_cpu = (x_src, x_dst) if bipartite else x_dst
+    with torch.no_grad():
+        want = oracle.attention_layer(sd, '', x_cpu, r, ei)
+        layer = layer.to(DEV)
+        x_gpu = (x_src.to(DEV), x_dst.to(DEV)) if bipartite else x_dst.to(DEV)
+        got = layer(x_gpu, None if r is None else r.to(DEV), ei.to(DEV))
+        # a prebuilt CSRGraph gives the same result as the raw edge_index
+        got2 = layer(x_gpu, None if r is None else r.to(DEV), CSRGraph.from_edge_index(ei.to(DEV), n_src, n_dst))
+    assert rel_err(got, want) < TOL
+    assert torch.equal(got, got2)
+
+
+def test_attention_layer_state_dict_keys_match_reference_names():
+    layer = AttentionLayer(hidden_dim=128, num_heads=8, head_dim=16, dropout=0.1, bipartite=False, has_pos_emb=True)
+    keys = set(layer.state_dict().keys())
+    # aliased prenorm of non-bipartite layers appears under both names
+    for k in ('to_q.weight', 'to_q.bias', 'to_k.weight', 'to_v.bias', 'to_k_r.weight', 'to_v_r.bias', 'to_s.weight',
+              'to_g.weight', 'to_out.bias', 'ff_mlp.0.weight', 'ff_mlp.3.bias', 'attn_prenorm_x_src.weight',
+              'attn_prenorm_x_dst.weight', 'attn_prenorm_r.bias', 'attn_postnorm.weight', 'ff_prenorm.bias',
+              'ff_postnorm.weight'):
+        assert k in keys, k
+    assert 'to_k.bias' not in keys and 'to_k_r.bias' not in keys
+    assert layer.to_g.weight.shape == (128, 256) and layer.ff_mlp[0].weight.shape == (512, 128)
+    assert layer.attn_prenorm_x_dst is layer.attn_prenorm_x_src
+    assert len(list(layer.parameters())) == len(keys) - 2

@@ -1,0 +1,132 @@
+"""GPU parity: edge construction is bit-exact against the oracle (BASELINE.json: "bit-exact edge_index")."""
+import pytest
+import torch
+
+from helpers import c_radius, oracle
+
+import tempenslearnagg_qcnet_amd as pkg
+from tempenslearnagg_qcnet_amd import ops
+from tempenslearnagg_qcnet_amd.utils import graph as G
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _points(n, extent, seed, dim=2):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(n, dim, generator=g) * 2 - 1) * extent
+
+
+def _ptr(sizes):
+    p = torch.zeros(len(sizes) + 1, dtype=torch.int64)
+    p[1:] = torch.tensor(sizes).cumsum(0)
+    return p
+
+
+@pytest.mark.parametrize('sizes_x,sizes_y,r,cap,dim', [
+    ([50], [150], 50.0, 300, 2),
+    ([50, 37, 0, 64], [150, 90, 10, 0], 60.0, 300, 2),          # ragged + empty examples
+    ([200, 180], [400, 350], 100.0, 32, 2),                       # cap truncation (lowest x indices survive)
+    ([33, 21], [40, 17], 70.0, 8, 3),
+])
+def test_radius_bit_exact(sizes_x, sizes_y, r, cap, dim):
+    x = _points(sum(sizes_x), 100.0, 1, dim)
+    y = _points(sum(sizes_y), 100.0, 2, dim)
+    px, py = _ptr(sizes_x), _ptr(sizes_y)
+    want = c_radius(x, y, r, px, py, cap)
+    got, off = ops.radius_pairs(x.to(DEV), y.to(DEV), r, px.to(DEV), py.to(DEV), cap)
+    assert got.dtype == torch.int64
+    assert torch.equal(got.cpu(), want)
+    # offset is the CSR pointer over y
+    counts = torch.bincount(want[0], minlength=y.size(0))
+    assert torch.equal(off.cpu()[1:] - off.cpu()[:-1], counts)
+    # the torch restatement agrees with the C restatement (pins the two oracle forms to each other)
+    bx = torch.repeat_interleave(torch.arange(len(sizes_x)), torch.tensor(sizes_x))
+    by = torch.repeat_interleave(torch.arange(len(sizes_y)), torch.tensor(sizes_y))
+    if len(sizes_x) > 1 and sizes_x[-1] > 0 and sizes_y[-1] > 0:
+        assert torch.equal(oracle.radius(x, y, r, bx, by, cap), want)
+
+
+def test_radius_on_boundary_distances():
+    # integer lattice: many pairs sit exactly on d^2 == r^2 (strict '<' must drop them)
+    xs = torch.stack(torch.meshgrid(torch.arange(-6., 7.), torch.arange(-6., 7.), indexing='ij'), -1).reshape(-1, 2)
+    p = _ptr([xs.size(0)])
+    want = c_radius(xs, xs, 5.0, p, p, 1000)
+    got, _ = ops.radius_pairs(xs.to(DEV), xs.to(DEV), 5.0, p.to(DEV), p.to(DEV), 1000)
+    assert torch.equal(got.cpu(), want)
+    d2 = ((xs[want[0]] - xs[want[1]]) ** 2).sum(-1)
+    assert float(d2.max()) < 25.0
+
+
+def test_radius_api_matches_oracle_batched():
+    x, y = _points(300, 80.0, 3), _points(500, 80.0, 4)
+    bx = torch.repeat_interleave(torch.arange(4), torch.tensor([70, 80, 90, 60]))
+    by = torch.repeat_interleave(torch.arange(4), torch.tensor([100, 150, 120, 130]))
+    want = oracle.radius(x, y, 40.0, bx, by, 300)
+    got = G.radius(x.to(DEV), y.to(DEV), 40.0, bx.to(DEV), by.to(DEV), max_num_neighbors=300)
+    assert torch.equal(got.cpu(), want)
+    want_g = oracle.radius_graph(x, 40.0, bx, loop=False, max_num_neighbors=300)
+    got_g = G.radius_graph(x.to(DEV), 40.0, bx.to(DEV), loop=False, max_num_neighbors=300)
+    assert torch.equal(got_g.cpu(), want_g)
+    # unbatched, with the cap biting: a target keeps 'cap' others only if its own index is among its first cap+1 hits
+    want_c = oracle.radius_graph(x, 60.0, None, loop=False, max_num_neighbors=16)
+    got_c = G.radius_graph(x.to(DEV), 60.0, None, loop=False, max_num_neighbors=16)
+    assert torch.equal(got_c.cpu(), want_c)
+    deg = torch.bincount(want_c[1], minlength=300)
+    assert int(deg.max()) == 17 and int(deg.min()) >= 16   # the G2 quirk: 16 or 17 survivors
+
+
+def test_radius_fused_filters_equal_post_filtering():
+    x = _points(400, 60.0, 5)
+    p = _ptr([150, 250])
+    g = torch.Generator().manual_seed(6)
+    mask = torch.rand(400, generator=g) > 0.3
+    base = oracle.radius_graph(x, 25.0, torch.repeat_interleave(torch.arange(2), torch.tensor([150, 250])),
+                               loop=False, max_num_neighbors=20)
+    want = oracle.subgraph(mask, base)
+    got, off = ops.radius_pairs(x.to(DEV), x.to(DEV), 25.0, p.to(DEV), p.to(DEV), 21, drop_self=True,
+                                mask_x=mask.to(DEV), mask_y=mask.to(DEV), y_first=False)
+    assert torch.equal(got.cpu(), want)
+    assert int(off[-1]) == want.size(1)
+
+
+def test_radius_empty_inputs():
+    e = G.radius(torch.empty(0, 2, device=DEV), torch.rand(5, 2, device=DEV), 1.0)
+    assert e.shape == (2, 0) and e.dtype == torch.int64
+    x = torch.rand(5, 2, device=DEV) * 100
+    e2 = G.radius(x, x + 1000.0, 1.0)
+    assert e2.shape == (2, 0)
+
+
+def test_csr_build_matches_stable_sort():
+    g = torch.Generator().manual_seed(7)
+    n_src, n_dst, E = 1000, 777, 50000
+    ei = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)])
+    ei[1, :100] = 5                                            # a heavy destination
+    rowptr, col, eid = ops.csr_build(ei.to(DEV), n_dst)
+    order = torch.sort(ei[1], stable=True)[1]
+    assert torch.equal(eid.cpu().long(), order)
+    assert torch.equal(col.cpu().long(), ei[0][order])
+    want_ptr = torch.zeros(n_dst + 1, dtype=torch.long)
+    want_ptr[1:] = torch.bincount(ei[1], minlength=n_dst).cumsum(0)
+    assert torch.equal(rowptr.cpu().long(), want_ptr)
+    # empty edge list
+    rp, c, e = ops.csr_build(torch.empty(2, 0, dtype=torch.long, device=DEV), 10)
+    assert torch.equal(rp.cpu(), torch.zeros(11, dtype=torch.int32)) and c.numel() == 0
+
+
+def test_dense_to_sparse_and_coalesce_match_oracle():
+    g = torch.Generator().manual_seed(8)
+    adj = torch.rand(5, 7, 7, generator=g) > 0.6
+    assert torch.equal(G.dense_to_sparse(adj.to(DEV))[0].cpu(), oracle.dense_to_sparse(adj))
+    adj2 = torch.rand(5, 7, 3, generator=g) > 0.5
+    assert torch.equal(G.bipartite_dense_to_sparse(adj2.to(DEV)).cpu(), oracle.bipartite_dense_to_sparse(adj2))
+    ei = torch.randint(0, 30, (2, 400), generator=g)
+    attr = torch.randint(0, 5, (400,), generator=g).to(torch.uint8)
+    wi, wa = oracle.coalesce_max(ei, attr)
+    gi, ga = G.merge_edges([ei[:, :150].to(DEV), ei[:, 150:].to(DEV)], [attr[:150].to(DEV), attr[150:].to(DEV)],
+                           reduce='max')
+    assert torch.equal(gi.cpu(), wi) and torch.equal(ga.cpu(), wa)
+    # lexicographically sorted and unique
+    key = wi[0] * 30 + wi[1]
+    assert bool((key[1:] > key[:-1]).all())

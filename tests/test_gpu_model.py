@@ -1,0 +1,134 @@
+"""GPU parity of the module stack and the full TempEnsLearnAgg loop against the CPU oracle."""
+import pytest
+import torch
+
+from helpers import cpu_state_dict, load_golden, oracle, randomize_, rel_err
+
+from tempenslearnagg_qcnet_amd.layers import FourierEmbedding, MLPLayer
+from tempenslearnagg_qcnet_amd.predictors import QCNetSliding, TempEnsLearnAgg
+from tempenslearnagg_qcnet_amd.synthetic import HPARAMS_AV2, SCENE_AV2, config_scene, make_batch, make_scenario
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+TOL = 1e-4   # BASELINE.json north_star: fp32 trajectories / probabilities within 1e-4 relative
+
+EDGE_KEYS_ENC = ('edge_index_pl2pl', 'edge_index_t', 'edge_index_pl2a', 'edge_index_a2a')
+EDGE_KEYS_DEC = ('edge_index_t2m', 'edge_index_pl2m', 'edge_index_a2m', 'edge_index_m2m', 'edge_index_pl2m_clone')
+OUT_KEYS = ('loc_propose_pos', 'scale_propose_pos', 'loc_refine_pos', 'scale_refine_pos', 'pi')
+
+
+@pytest.mark.parametrize('tag', ['fe0_c2', 'fe1_c2', 'fe2_c0', 'fe3_c0', 'fe3_c1', 'fe4_c1', 'fe4_c0'])
+def test_fourier_embedding_vs_reference_golden(tag):
+    g = load_golden('ref_layers.npz')
+    in_dim = int(tag[2])
+    m = FourierEmbedding(input_dim=in_dim, hidden_dim=128, num_freq_bands=64).eval()
+    m.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + '.sd.')})
+    m = m.to(DEV)
+    cont = torch.from_numpy(g[tag + '.cont']).to(DEV) if in_dim else None
+    cats = [torch.from_numpy(g['%s.cat%d' % (tag, i)]).to(DEV) for i in range(int(tag[-1]))] or None
+    with torch.no_grad():
+        got = m(continuous_inputs=cont, categorical_embs=cats)
+    assert rel_err(got, torch.from_numpy(g[tag + '.out'])) < TOL
+
+
+@pytest.mark.parametrize('out_dim', [1, 40, 120])
+def test_mlp_layer_vs_reference_golden(out_dim):
+    g = load_golden('ref_layers.npz')
+    tag = 'mlp%d' % out_dim
+    m = MLPLayer(input_dim=128, hidden_dim=128, output_dim=out_dim).eval()
+    m.load_state_dict({k[len(tag) + 4:]: torch.from_numpy(g[k]) for k in g.files if k.startswith(tag + '.sd.')})
+    with torch.no_grad():
+        got = m.to(DEV)(torch.from_numpy(g[tag + '.x']).to(DEV))
+    assert rel_err(got, torch.from_numpy(g[tag + '.out'])) < TOL
+
+
+def _model(cfg, seed=0):
+    torch.manual_seed(seed)
+    model = randomize_(TempEnsLearnAgg(**cfg['hparams']), seed=seed + 1).eval()
+    # the aggregation layer starts as a copy of the decoder (predictors/temp_ens_learn_agg.py:81); give it its
+    # own values so the test can tell the two apart
+    randomize_(model.temporal_aggregate_layer, seed=seed + 2)
+    return model
+
+
+def _check_edges(got, want, keys):
+    for k in keys:
+        assert got[k].dtype == torch.int64
+        assert torch.equal(got[k].cpu(), want[k]), k
+
+
+@pytest.mark.parametrize('cfg_name,ids,time_shift', [('tiny', [0, 1, 2], 10), ('tiny', [5], 1)])
+def test_qcnet_forward_vs_oracle_small(cfg_name, ids, time_shift):
+    cfg = config_scene(cfg_name)
+    model = _model(cfg)
+    sd = cpu_state_dict(model)
+    batch = make_batch(ids, **cfg['scene'])
+    with torch.no_grad():
+        want_pred, want_enc = oracle.qcnet_forward(sd, batch, time_shift, cfg['hparams'], p='base_model.')
+        got_pred, got_enc = model.to(DEV)(batch.to(DEV), time_shift)
+    _check_edges(got_enc, want_enc, EDGE_KEYS_ENC)
+    _check_edges(got_pred, want_pred, EDGE_KEYS_DEC)
+    assert rel_err(got_enc['x_a'], want_enc['x_a']) < TOL
+    assert rel_err(got_enc['x_pl'][:, 0], want_enc['x_pl'][:, 0]) < TOL
+    assert got_enc['x_pl'].shape == want_enc['x_pl'].shape
+    for k in OUT_KEYS + ('m',):
+        assert got_pred[k].shape == want_pred[k].shape, k
+        assert rel_err(got_pred[k], want_pred[k]) < TOL, k
+
+
+def test_qcnet_forward_vs_oracle_cfg1_scene():
+    """One full-size AV2-shaped scenario (BASELINE.json configs[0] scene: 50 agents, 150 polygons)."""
+    model = _model(dict(hparams=HPARAMS_AV2))
+    sd = cpu_state_dict(model)
+    batch = make_batch([0], **SCENE_AV2)
+    with torch.no_grad():
+        want_pred, want_enc = oracle.qcnet_forward(sd, batch, 10, HPARAMS_AV2, p='base_model.')
+        got_pred, got_enc = model.to(DEV)(batch.to(DEV), 10)
+    _check_edges(got_enc, want_enc, EDGE_KEYS_ENC)
+    _check_edges(got_pred, want_pred, EDGE_KEYS_DEC)
+    for k in OUT_KEYS + ('m',):
+        assert rel_err(got_pred[k], want_pred[k]) < TOL, k
+
+
+def test_unbatched_scenario_matches_batch_of_one():
+    cfg = config_scene('tiny')
+    model = _model(cfg).to(DEV)
+    single = make_scenario(3, **cfg['scene']).to(DEV)          # HeteroData, not a Batch (isinstance switches)
+    batch = make_batch([3], **cfg['scene']).to(DEV)
+    with torch.no_grad():
+        a, _ = model(single, 4)
+        b, _ = model(batch, 4)
+    for k in OUT_KEYS:
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_temp_ens_learn_agg_vs_oracle():
+    """BASELINE.json configs[2] at oracle-sized scenes: ten sliding frames + TemporalAggregate."""
+    cfg = config_scene('tiny')
+    model = _model(cfg)
+    sd = cpu_state_dict(model)
+    batch = make_batch([0, 1], **cfg['scene'])
+    with torch.no_grad():
+        want = oracle.temp_ens_learn_agg_forward(sd, batch, cfg['hparams'])
+        model = model.to(DEV)
+        got = model.predict(batch.to(DEV))
+        model.share_map_encoding = False                       # the reference's own loop (map encoder per frame)
+        got_ref_loop = model.predict(batch.to(DEV))
+    for k in ('traj_refine', 'pi_softmax', 'final_m', 'loc_refine_pos', 'scale_refine_pos', 'pi'):
+        assert rel_err(got[k], want[k]) < TOL, k
+        assert torch.equal(got[k], got_ref_loop[k]), k
+    assert got['traj_refine'].shape == (batch['agent']['num_nodes'], 6, 50, 4)
+    assert torch.allclose(got['pi_softmax'].sum(-1), torch.ones(batch['agent']['num_nodes'], device=DEV), atol=1e-5)
+
+
+def test_scenarios_are_independent_full_size():
+    """Size-independent property at the full bench batch shape: a scenario's prediction does not depend on
+    what else is in the batch (scenario sharding across GPUs relies on it)."""
+    model = _model(dict(hparams=HPARAMS_AV2)).to(DEV)
+    ids = list(range(8))
+    with torch.no_grad():
+        full, _ = model(make_batch(ids, **SCENE_AV2).to(DEV), 7)
+        part, _ = model(make_batch(ids[5:7], **SCENE_AV2).to(DEV), 7)
+    A = SCENE_AV2['num_agents']
+    for k in OUT_KEYS:
+        assert rel_err(full[k][5 * A:7 * A], part[k]) < 1e-5, k
