@@ -1,0 +1,164 @@
+"""CPU: the oracle against the reference's own outputs (tests/golden/ref_layers.npz, written by
+oracle/make_golden.py from /root/reference's layers/fourier_embedding.py, layers/mlp_layer.py, utils/geometry.py,
+utils/weight_init.py) and against independent restatements of the third-party semantics."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import c_attention, c_radius, load_golden, oracle
+
+from tempenslearnagg_qcnet_amd.utils import geometry as prod_geo
+from tempenslearnagg_qcnet_amd.utils.weight_init import weight_init
+
+G = load_golden('ref_layers.npz')
+
+
+def _sd(tag):
+    return {k[len(tag) + 4:]: torch.from_numpy(G[k]) for k in G.files if k.startswith(tag + '.sd.')}
+
+
+@pytest.mark.parametrize('tag', ['fe0_c2', 'fe1_c2', 'fe2_c0', 'fe3_c0', 'fe3_c1', 'fe4_c1', 'fe4_c0'])
+def test_oracle_fourier_embedding_matches_reference(tag):
+    in_dim, n_cat = int(tag[2]), int(tag[-1])
+    cont = torch.from_numpy(G[tag + '.cont']) if in_dim else None
+    cats = [torch.from_numpy(G['%s.cat%d' % (tag, i)]) for i in range(n_cat)] or None
+    got = oracle.fourier_embedding(_sd(tag), '', cont, cats)
+    want = torch.from_numpy(G[tag + '.out'])
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('out_dim', [1, 40, 120])
+def test_oracle_mlp_layer_matches_reference(out_dim):
+    tag = 'mlp%d' % out_dim
+    got = oracle.mlp_layer(_sd(tag), '', torch.from_numpy(G[tag + '.x']))
+    want = torch.from_numpy(G[tag + '.out'])
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+def test_geometry_matches_reference_bitwise():
+    ctr, nbr, ang = (torch.from_numpy(G[k]) for k in ('geo_ctr', 'geo_nbr', 'geo_angle_in'))
+    for impl in (oracle, prod_geo):
+        assert torch.equal(impl.angle_between_2d_vectors(ctr, nbr), torch.from_numpy(G['geo_angle_between']))
+        assert torch.equal(impl.wrap_angle(ang), torch.from_numpy(G['geo_wrap']))
+    w = oracle.wrap_angle(ang)
+    assert float(w.min()) >= -math.pi - 1e-6 and float(w.max()) < math.pi + 1e-6
+
+
+def test_weight_init_rules_match_reference_statistics():
+    lin = torch.nn.Linear(128, 384)
+    weight_init(lin)
+    bound = (6.0 / (128 + 384)) ** 0.5
+    assert float(lin.weight.abs().max()) <= bound and float(lin.bias.abs().max()) == float(G['wi_linear_bias_absmax']) == 0.0
+    assert abs(float(lin.weight.abs().max()) - float(G['wi_linear_absmax'])) < 0.01 * bound
+    gru = torch.nn.GRU(128, 128)
+    weight_init(gru)
+    for w in gru.weight_hh_l0.detach().chunk(3, 0):
+        assert float((w @ w.t() - torch.eye(128)).abs().max()) < 1e-4
+    assert float(G['wi_gru_hh_orth_err']) < 1e-4 and float(G['wi_gru_bias_absmax']) == 0.0
+    assert float(gru.bias_ih_l0.abs().max()) == 0.0 and float(gru.bias_hh_l0.abs().max()) == 0.0
+    ln, emb = torch.nn.LayerNorm(128), torch.nn.Embedding(1000, 128)
+    weight_init(ln), weight_init(emb)
+    assert bool((ln.weight == 1).all()) and bool((ln.bias == 0).all())
+    assert abs(float(emb.weight.std()) - 0.02) < 0.002
+
+
+def test_oracle_gru_matches_torch_gru():
+    torch.manual_seed(0)
+    gru = torch.nn.GRU(128, 128).eval()
+    with torch.no_grad():
+        for p in gru.parameters():
+            p.copy_(torch.randn_like(p) * 0.1)
+    seq, h0 = torch.randn(60, 17, 128), torch.randn(17, 128) * 0.3
+    with torch.no_grad():
+        want = gru(seq, h0.unsqueeze(0))[1].squeeze(0)
+    sd = {'traj_emb.' + k: v.detach() for k, v in gru.state_dict().items()}
+    got = oracle.gru_last_hidden(sd, 'traj_emb.', seq, h0)
+    assert float((got - want).abs().max()) < 2e-6
+
+
+def test_oracle_radius_torch_form_equals_c_form():
+    g = torch.Generator().manual_seed(0)
+    sizes_x, sizes_y = [40, 0, 55, 31], [60, 20, 0, 44]
+    x = (torch.rand(sum(sizes_x), 2, generator=g) - 0.5) * 100
+    y = (torch.rand(sum(sizes_y), 2, generator=g) - 0.5) * 100
+    # put some points exactly r apart (strict inequality) and almost r apart
+    y[0] = x[0] + torch.tensor([30.0, 40.0])
+    y[1] = x[1] + torch.tensor([30.0, 40.000004])
+    bx = torch.repeat_interleave(torch.arange(4), torch.tensor(sizes_x))
+    by = torch.repeat_interleave(torch.arange(4), torch.tensor(sizes_y))
+    px = torch.tensor([0] + list(np.cumsum(sizes_x)))
+    py = torch.tensor([0] + list(np.cumsum(sizes_y)))
+    for r, cap in ((50.0, 300), (50.0, 7), (12.5, 300)):
+        a = oracle.radius(x, y, r, bx, by, cap)
+        b = c_radius(x, y, r, px, py, cap)
+        assert torch.equal(a, b)
+        # brute-force property: every returned pair is within r, same example, y ascending, x ascending inside a y
+        d2 = ((x[a[1]] - y[a[0]]).double() ** 2).sum(-1)
+        assert bool((d2 < r * r * (1 + 1e-6)).all()) and torch.equal(bx[a[1]], by[a[0]])
+        key = a[0] * 10000 + a[1]
+        assert bool((key[1:] > key[:-1]).all())
+        assert int(torch.bincount(a[0]).max()) <= cap
+
+
+def test_oracle_radius_graph_semantics():
+    g = torch.Generator().manual_seed(1)
+    x = (torch.rand(120, 2, generator=g) - 0.5) * 60
+    ei = oracle.radius_graph(x, 20.0, None, loop=False, max_num_neighbors=300)
+    d = torch.cdist(x.double(), x.double())
+    want = ((d < 20.0) & ~torch.eye(120, dtype=torch.bool)).t().nonzero().t()      # grouped by target, source ascending
+    assert torch.equal(ei, torch.stack([want[1], want[0]]))
+    assert not bool((ei[0] == ei[1]).any())
+
+
+def test_oracle_segment_softmax_and_attention_vs_fp64():
+    g = torch.Generator().manual_seed(2)
+    E, nd, ns = 4000, 120, 90
+    ei = torch.stack([torch.randint(0, ns, (E,), generator=g), torch.randint(0, nd - 10, (E,), generator=g)])
+    sim = torch.randn(E, 8, generator=g) * 5
+    a = oracle.segment_softmax(sim, ei[1])
+    sums = torch.zeros(nd, 8).index_add_(0, ei[1], a)
+    deg = torch.bincount(ei[1], minlength=nd)
+    assert torch.allclose(sums[deg > 0], torch.ones_like(sums[deg > 0]), atol=1e-5)
+    # attention_layer's propagate part against the independent fp64 C restatement
+    q, k, v = torch.randn(nd, 128, generator=g), torch.randn(ns, 128, generator=g), torch.randn(ns, 128, generator=g)
+    kr, vr = torch.randn(E, 128, generator=g) * 0.5, torch.randn(E, 128, generator=g) * 0.5
+    H, D = 8, 16
+    kj = (k[ei[0]] + kr).view(-1, H, D)
+    vj = (v[ei[0]] + vr).view(-1, H, D)
+    s = (q[ei[1]].view(-1, H, D) * kj).sum(-1) * D ** -0.5
+    agg = torch.zeros(nd, H, D).index_add_(0, ei[1], vj * oracle.segment_softmax(s, ei[1]).unsqueeze(-1))
+    want = c_attention(q, k, v, kr, vr, ei)
+    assert float((agg.view(nd, 128).double() - want).abs().max()) < 1e-5
+    assert bool((agg.view(nd, 128)[deg == 0] == 0).all())
+
+
+def test_oracle_graph_utilities():
+    adj = torch.zeros(2, 3, 3, dtype=torch.bool)
+    adj[0, 0, 1] = adj[0, 2, 0] = adj[1, 1, 1] = adj[1, 2, 0] = True
+    assert oracle.dense_to_sparse(adj).tolist() == [[0, 2, 4, 5], [1, 0, 4, 3]]
+    adj2 = torch.zeros(2, 3, 2, dtype=torch.bool)
+    adj2[0, 1, 1] = adj2[1, 0, 0] = adj2[1, 2, 1] = True
+    assert oracle.bipartite_dense_to_sparse(adj2).tolist() == [[1, 3, 5], [1, 2, 3]]
+    ei = torch.tensor([[3, 0, 3, 1, 0], [1, 2, 1, 1, 2]])
+    idx, attr = oracle.coalesce_max(ei, torch.tensor([1, 0, 4, 2, 3], dtype=torch.uint8))
+    assert idx.tolist() == [[0, 1, 3], [2, 1, 1]] and attr.tolist() == [3, 2, 4] and attr.dtype == torch.uint8
+    mask = torch.tensor([True, False, True, True])
+    assert oracle.subgraph(mask, ei).tolist() == [[0, 0], [2, 2]]
+
+
+def test_oracle_full_forward_runs_and_is_batch_consistent():
+    """Scenario independence in the oracle itself: a batch of two equals the two scenarios run alone."""
+    from tempenslearnagg_qcnet_amd.predictors import TempEnsLearnAgg
+    from tempenslearnagg_qcnet_amd.synthetic import config_scene, make_batch
+    cfg = config_scene('tiny')
+    torch.manual_seed(0)
+    sd = {k: v.detach() for k, v in TempEnsLearnAgg(**cfg['hparams']).state_dict().items()}
+    with torch.no_grad():
+        both, _ = oracle.qcnet_forward(sd, make_batch([0, 1], **cfg['scene']), 3, cfg['hparams'], p='base_model.')
+        one, _ = oracle.qcnet_forward(sd, make_batch([1], **cfg['scene']), 3, cfg['hparams'], p='base_model.')
+    A = cfg['scene']['num_agents']
+    assert float((both['loc_refine_pos'][A:] - one['loc_refine_pos']).abs().max()) < 1e-4
+    assert float((both['pi'][A:] - one['pi']).abs().max()) < 1e-4

@@ -1,0 +1,61 @@
+"""CPU, world_size 2 over gloo: scenario sharding, the prediction all_gather and the metric all_reduce.
+The forward is replaced by a cheap deterministic stand-in (the HIP path needs a GPU); what is under test is the
+partitioning and the two collectives."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import ROOT
+
+from tempenslearnagg_qcnet_amd import sharding
+from tempenslearnagg_qcnet_amd.synthetic import SCENE_TINY, make_batch
+
+
+def _fake_predict(data):
+    focal = data['agent']['position'][:, 59, :2]
+    A = focal.size(0)
+    traj = focal.view(A, 1, 1, 2).expand(A, 6, 50, 2) + torch.arange(6).view(1, 6, 1, 1) * 0.5
+    pi = focal[:, :1].expand(A, 6) * torch.arange(6)
+    return {'traj_refine': torch.cat([traj, torch.ones_like(traj)], dim=-1), 'pi_softmax': torch.softmax(pi, -1)}
+
+
+def _worker(rank, world, port, num_scenarios, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    recs, sums = sharding.run_sharded(_fake_predict, lambda ids: make_batch(ids, **SCENE_TINY), num_scenarios, 3,
+                                      rank, world, torch.device('cpu'))
+    torch.save({'records': recs, 'sums': sums}, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_run_equals_single_process(tmp_path):
+    num_scenarios, world = 7, 2                                           # ragged: 4 + 3 scenarios
+    mp.spawn(_worker, args=(world, _free_port(), num_scenarios, str(tmp_path)), nprocs=world, join=True)
+    single_recs, single_sums = sharding.run_sharded(_fake_predict, lambda ids: make_batch(ids, **SCENE_TINY),
+                                                    num_scenarios, 3, 0, 1, torch.device('cpu'))
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r))
+        assert got['records'].shape == (num_scenarios, sharding.RECORD_WIDTH)
+        assert got['records'][:, 0].tolist() == list(range(num_scenarios))
+        assert torch.equal(got['records'], single_recs)                   # bit-identical to the 1-process run
+        assert torch.allclose(got['sums'], single_sums, rtol=1e-6)
+        assert got['sums'][1] == num_scenarios
+
+
+def test_partition_is_a_disjoint_cover():
+    for world in (1, 2, 4, 8):
+        ids = [i for r in range(world) for i in sharding.shard_scenario_ids(10000, r, world)]
+        assert sorted(ids) == list(range(10000))
+    assert sharding.batches(list(range(7)), 3) == [[0, 1, 2], [3, 4, 5], [6]]
