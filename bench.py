@@ -103,7 +103,8 @@ def main() -> None:
         barrier()
         elapsed = time.perf_counter() - t0
         ops.prof_enable(False)
-    launches, attn_ms, attn_bytes = ops.prof_collect()
+    launches, attn_ms, attn_bytes = ops.prof_collect(ops.PROF_ATTN_FUSED)
+    ops.prof_collect(-1)
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -123,11 +124,11 @@ def main() -> None:
                                    'fp32 weights' % (args.config, batch_size, cfg['scene']['num_agents'],
                                                      cfg['scene']['num_polygons']),
                        'global_batch': world * batch_size, 'parallelism': 'scenario-sharded x%d' % world},
-            'roofline': {'bound': 'hbm', 'kernel': 'attn_fwd_kernel (qcn_attn_fwd_f32)', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': 'attn_fused_kernel (qcn_attn_fused_f32)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': launches, 'avg_launch_us': attn_ms * 1e3 / max(launches, 1),
                          'alg_bytes_per_launch': attn_bytes / max(launches, 1),
-                         'formula': '2064*E + 1024*n_dst (pos-emb) / 1040*E + 1024*n_dst (m2m)', 'traffic': None},
+                         'formula': '1552*E + 1024*n_dst (SURVEY 8(d), r-projection fused; E counts the reference\'s mode-replicated edges)', 'traffic': None},
             'gathered_records': int(gathered.size(0)), 'metric_sums': [float(x) for x in sums.tolist()],
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -100,12 +100,33 @@ int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, const float
                      const int32_t *rowptr, const int32_t *col, const int32_t *eid,
                      int64_t n_dst, int64_t n_src, int64_t num_edges, float *out, void *stream);
 
-/* Optional per-launch timing of qcn_attn_fwd_* with hipEvents on the launch stream (bench.py roofline leg).
- * qcn_prof_enable(1) starts recording, qcn_prof_collect synchronises the recorded events and returns the
- * number of launches, the summed kernel milliseconds and the summed algorithmic bytes
- * (2064*E + 1024*n_dst with pos-emb, 1040*E + 1024*n_dst without), then clears the log. */
+/* A3, fused positional form — same result as qcn_attn_fwd_f32 fed with kr = to_k_r(LN_r(r)), vr = to_v_r(LN_r(r))
+ * (layers/attention_layer.py:82,94-96), but the two per-edge projections are never materialised (algebra in
+ * csrc/attention_fused.hip).  rhat [E_base,128] = row-normalised r (qcn_row_normalize_f32: LN_r without its affine);
+ * wk[o][c] = to_k_r.weight[o][c] * gamma[c], wv[o][c] = to_v_r.weight[o][c] * gamma[c],
+ * bv = to_v_r.weight @ beta + to_v_r.bias  (gamma, beta = attn_prenorm_r affine), all fp32.
+ * Mode replication (modules/qcnet_decoder.py:170,190-192,208-211: K mode queries share one edge list and one r):
+ *   layout 0: n_rows == n_dst, rep == 1, destination node = CSR row;
+ *   layout 1: destination node = mode * n_rows + row   (mode-major, pl2m / a2m);
+ *   layout 2: destination node = row * rep + mode      (agent-major, t2m);   n_dst == n_rows * rep.
+ * rowptr [n_rows+1], col / eid [E_base] as in qcn_csr_build (eid NULL: rhat rows are in CSR order). */
+int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const float *rhat,
+                       const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *wk,
+                       const float *wv, const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows,
+                       int64_t num_edges, int rep, int layout, float *out, void *stream);
+
+/* K6 — y = (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine; the layer-independent half
+ * of attn_prenorm_r, layers/attention_layer.py:63,82). */
+int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);
+
+/* Optional per-launch timing of the hand-written kernels with hipEvents on the launch stream (bench.py roofline
+ * leg).  qcn_prof_enable(1) starts recording; qcn_prof_collect(kind, ...) synchronises the recorded events of one
+ * kernel family (0 = qcn_attn_fwd_f32, 1 = qcn_attn_fused_f32, ...; -1 = all) and returns the number of launches,
+ * the summed kernel milliseconds and the summed algorithmic units (bytes for the HBM-bound kernels:
+ * SURVEY.md §8(d) 2064*E + 1024*n_dst materialised, 1552*E + 1024*n_dst fused, 1040*E + 1024*n_dst without
+ * positional terms), then drops those records. */
 int qcn_prof_enable(int on);
-int qcn_prof_collect(int64_t *launches_host, double *millis_host, double *alg_bytes_host);
+int qcn_prof_collect(int kind, int64_t *launches_host, double *millis_host, double *alg_units_host);
 
 #ifdef __cplusplus
 }

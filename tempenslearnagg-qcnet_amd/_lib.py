@@ -38,16 +38,21 @@ def _declare(lib) -> None:
     lib.qcn_csr_build.argtypes = [P, P, c_int64, c_int64, P, P, P, P, c_size_t, P]
     lib.qcn_attn_fwd_f32.restype = c_int
     lib.qcn_attn_fwd_f32.argtypes = [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, P]
+    lib.qcn_attn_fused_f32.restype = c_int
+    lib.qcn_attn_fused_f32.argtypes = [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                                       P, P]
+    lib.qcn_row_normalize_f32.restype = c_int
+    lib.qcn_row_normalize_f32.argtypes = [P, P, c_int64, c_float, P]
     lib.qcn_prof_enable.restype = c_int
     lib.qcn_prof_enable.argtypes = [c_int]
     lib.qcn_prof_collect.restype = c_int
-    lib.qcn_prof_collect.argtypes = [POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
+    lib.qcn_prof_collect.argtypes = [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
 
 
 EXPORTED_SYMBOLS = (
     'qcn_version', 'qcn_status_string', 'qcn_radius_count', 'qcn_radius_fill', 'qcn_scan_workspace_bytes',
     'qcn_exclusive_scan_i32', 'qcn_csr_workspace_bytes', 'qcn_csr_build', 'qcn_attn_fwd_f32',
-    'qcn_prof_enable', 'qcn_prof_collect',
+    'qcn_attn_fused_f32', 'qcn_row_normalize_f32', 'qcn_prof_enable', 'qcn_prof_collect',
 )
 
 

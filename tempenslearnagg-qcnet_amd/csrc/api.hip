@@ -1,4 +1,68 @@
+#include <mutex>
+#include <vector>
+
 #include "common.hip.h"
+
+namespace {
+struct ProfRecord { hipEvent_t start, stop; double units; int kind; };
+std::mutex g_prof_mutex;
+std::vector<ProfRecord *> g_prof_log;
+bool g_prof_on = false;
+}  // namespace
+
+void *qcn_prof_begin(int kind, double alg_units, hipStream_t stream)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_prof_mutex);
+        if (!g_prof_on) return nullptr;
+    }
+    ProfRecord *rec = new ProfRecord();
+    rec->units = alg_units;
+    rec->kind = kind;
+    hipEventCreate(&rec->start);
+    hipEventCreate(&rec->stop);
+    hipEventRecord(rec->start, stream);
+    return rec;
+}
+
+void qcn_prof_end(void *token, hipStream_t stream)
+{
+    if (!token) return;
+    ProfRecord *rec = static_cast<ProfRecord *>(token);
+    hipEventRecord(rec->stop, stream);
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_log.push_back(rec);
+}
+
+extern "C" int qcn_prof_enable(int on)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    g_prof_on = on != 0;
+    return QCN_OK;
+}
+
+extern "C" int qcn_prof_collect(int kind, int64_t *launches_host, double *millis_host, double *alg_units_host)
+{
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
+    int64_t n = 0;
+    double ms = 0.0, units = 0.0;
+    std::vector<ProfRecord *> rest;
+    for (ProfRecord *r : g_prof_log) {
+        if (kind >= 0 && r->kind != kind) { rest.push_back(r); continue; }
+        float t = 0.f;
+        if (hipEventSynchronize(r->stop) == hipSuccess && hipEventElapsedTime(&t, r->start, r->stop) == hipSuccess) {
+            ++n; ms += t; units += r->units;
+        }
+        hipEventDestroy(r->start);
+        hipEventDestroy(r->stop);
+        delete r;
+    }
+    g_prof_log.swap(rest);
+    if (launches_host) *launches_host = n;
+    if (millis_host) *millis_host = ms;
+    if (alg_units_host) *alg_units_host = units;
+    return QCN_OK;
+}
 
 extern "C" int qcn_version(void) { return 100; }
 

@@ -7,9 +7,6 @@
 // at a time so up to 16 row loads are in flight per wave, and the softmax is the online (running max / running
 // sum) form, so every input byte is read exactly once and nothing but the [n_dst,128] result is written.
 // HBM-bound: 2064 B/edge + 1024 B/destination with positional terms.
-#include <mutex>
-#include <vector>
-
 #include "common.hip.h"
 
 namespace {
@@ -97,40 +94,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
     *reinterpret_cast<float2 *>(out + node * kC + 2 * lane) = make_float2(acc.x * inv, acc.y * inv);
 }
 
-// ---- optional per-launch event timing (bench.py roofline leg) ------------------------------------
-struct ProfRecord { hipEvent_t start, stop; double bytes; };
-std::mutex g_prof_mutex;
-std::vector<ProfRecord> g_prof_log;
-bool g_prof_on = false;
-
 }  // namespace
-
-extern "C" int qcn_prof_enable(int on)
-{
-    std::lock_guard<std::mutex> lock(g_prof_mutex);
-    g_prof_on = on != 0;
-    return QCN_OK;
-}
-
-extern "C" int qcn_prof_collect(int64_t *launches_host, double *millis_host, double *alg_bytes_host)
-{
-    std::lock_guard<std::mutex> lock(g_prof_mutex);
-    int64_t n = 0;
-    double ms = 0.0, bytes = 0.0;
-    for (ProfRecord &r : g_prof_log) {
-        float t = 0.f;
-        if (hipEventSynchronize(r.stop) == hipSuccess && hipEventElapsedTime(&t, r.start, r.stop) == hipSuccess) {
-            ++n; ms += t; bytes += r.bytes;
-        }
-        hipEventDestroy(r.start);
-        hipEventDestroy(r.stop);
-    }
-    g_prof_log.clear();
-    if (launches_host) *launches_host = n;
-    if (millis_host) *millis_host = ms;
-    if (alg_bytes_host) *alg_bytes_host = bytes;
-    return QCN_OK;
-}
 
 extern "C" int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, const float *kr, const float *vr,
                                 const int32_t *rowptr, const int32_t *col, const int32_t *eid, int64_t n_dst,
@@ -147,18 +111,7 @@ extern "C" int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, 
     const unsigned grid = (unsigned)((n_dst + 3) / 4);
     const bool has_r = kr != nullptr && num_edges > 0;
 
-    bool prof = false;
-    ProfRecord rec{};
-    {
-        std::lock_guard<std::mutex> lock(g_prof_mutex);
-        prof = g_prof_on;
-    }
-    if (prof) {
-        hipEventCreate(&rec.start);
-        hipEventCreate(&rec.stop);
-        rec.bytes = (has_r ? 2064.0 : 1040.0) * (double)num_edges + 1024.0 * (double)n_dst;
-        hipEventRecord(rec.start, s);
-    }
+    void *token = qcn_prof_begin(QCN_PROF_ATTN, (has_r ? 2064.0 : 1040.0) * (double)num_edges + 1024.0 * (double)n_dst, s);
     if (has_r) {
         if (eid)
             hipLaunchKernelGGL((attn_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, s, q, k, v, kr, vr, rowptr, col,
@@ -171,10 +124,6 @@ extern "C" int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, 
                            eid, n_dst, out);
     }
     const bool ok = hipGetLastError() == hipSuccess;
-    if (prof) {
-        hipEventRecord(rec.stop, s);
-        std::lock_guard<std::mutex> lock(g_prof_mutex);
-        g_prof_log.push_back(rec);
-    }
+    qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }

@@ -137,6 +137,46 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kr: Optional[tor
     return out
 
 
+def row_normalize(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """qcn_row_normalize_f32: (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine)."""
+    dev = x.device
+    _require(x, 'x', torch.float32, dev, (None, C))
+    y = torch.empty_like(x)
+    _lib.check(_lib.lib().qcn_row_normalize_f32(_ptr(x), _ptr(y), x.size(0), float(eps), _stream(dev)),
+               'qcn_row_normalize_f32')
+    return y
+
+
+LAYOUT_PLAIN, LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR = 0, 1, 2
+
+
+def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Tensor, rowptr: torch.Tensor,
+               col: torch.Tensor, eid: Optional[torch.Tensor], wk: torch.Tensor, wv: torch.Tensor, bv: torch.Tensor,
+               rep: int = 1, layout: int = LAYOUT_PLAIN) -> torch.Tensor:
+    """qcn_attn_fused_f32: attention propagate with the positional projections folded into the kernel."""
+    dev = q.device
+    n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
+    n_rows = rowptr.numel() - 1
+    _require(q, 'q', torch.float32, dev, (n_dst, C))
+    _require(k, 'k', torch.float32, dev, (n_src, C))
+    _require(v, 'v', torch.float32, dev, (n_src, C))
+    _require(rhat, 'rhat', torch.float32, dev, (num_edges, C))
+    _require(rowptr, 'rowptr', torch.int32, dev, (n_rows + 1,))
+    _require(col, 'col', torch.int32, dev, (num_edges,))
+    if eid is not None:
+        _require(eid, 'eid', torch.int32, dev, (num_edges,))
+    _require(wk, 'wk', torch.float32, dev, (C, C))
+    _require(wv, 'wv', torch.float32, dev, (C, C))
+    _require(bv, 'bv', torch.float32, dev, (C,))
+    if n_rows * rep != n_dst or (layout == LAYOUT_PLAIN and rep != 1):
+        raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d)' % (n_rows, rep, n_dst))
+    out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_attn_fused_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat), _ptr(rowptr), _ptr(col), _ptr(eid),
+                                             _ptr(wk), _ptr(wv), _ptr(bv), n_dst, n_src, n_rows, num_edges, int(rep),
+                                             int(layout), _ptr(out), _stream(dev)), 'qcn_attn_fused_f32')
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # profiling hooks for bench.py
 # ------------------------------------------------------------------------------------------------
@@ -144,7 +184,12 @@ def prof_enable(on: bool) -> None:
     _lib.check(_lib.lib().qcn_prof_enable(int(bool(on))), 'qcn_prof_enable')
 
 
-def prof_collect() -> Tuple[int, float, float]:
+PROF_ATTN, PROF_ATTN_FUSED, PROF_FOURIER, PROF_GEMM = 0, 1, 2, 3
+
+
+def prof_collect(kind: int = -1) -> Tuple[int, float, float]:
+    """(launches, summed kernel ms, summed algorithmic units) of one kernel family, then clears those records."""
     n, ms, b = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
-    _lib.check(_lib.lib().qcn_prof_collect(ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)), 'qcn_prof_collect')
+    _lib.check(_lib.lib().qcn_prof_collect(int(kind), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)),
+               'qcn_prof_collect')
     return int(n.value), float(ms.value), float(b.value)

@@ -19,22 +19,34 @@ from .. import ops
 
 class CSRGraph:
     """A bipartite relation src → dst in two forms: the reference-order COO ``edge_index`` ([2, E] int64)
-    and a destination-sorted CSR (``rowptr`` int32 [n_dst + 1], ``col`` int32 [E] source per slot,
-    ``eid`` int32 [E] original edge id per slot, or None when the COO order already is the CSR order)."""
+    and a destination-sorted CSR (``rowptr`` int32 [n_rows + 1], ``col`` int32 [E_base] source per slot,
+    ``eid`` int32 [E_base] original edge id per slot, or None when the COO order already is the CSR order).
 
-    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid')
+    Mode replication: the decoder attends with K mode queries per agent that share one edge list and one
+    positional embedding (modules/qcnet_decoder.py:170,190-192,208-211).  Such a relation is stored once
+    (``n_rows`` CSR rows, ``E_base`` edges) with ``rep = K`` and a ``layout`` telling where mode ``m`` of row
+    ``i`` lives in the destination tensor: ``LAYOUT_MODE_MAJOR`` → ``m * n_rows + i``, ``LAYOUT_AGENT_MAJOR`` →
+    ``i * rep + m``.  ``edge_index`` still holds the reference's replicated COO list (E = E_base * rep)."""
 
-    def __init__(self, edge_index, n_src, n_dst, rowptr, col, eid):
+    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid', 'rep', 'layout')
+
+    def __init__(self, edge_index, n_src, n_dst, rowptr, col, eid, rep: int = 1, layout: int = ops.LAYOUT_PLAIN):
         self.edge_index = edge_index
         self.n_src = int(n_src)
         self.n_dst = int(n_dst)
         self.rowptr = rowptr
         self.col = col
         self.eid = eid
+        self.rep = int(rep)
+        self.layout = int(layout)
+
+    @property
+    def num_base_edges(self) -> int:
+        return int(self.col.numel())
 
     @property
     def num_edges(self) -> int:
-        return int(self.col.numel())
+        return int(self.col.numel()) * self.rep
 
     @classmethod
     def from_edge_index(cls, edge_index: torch.Tensor, n_src: int, n_dst: int, validate: bool = True) -> 'CSRGraph':
@@ -51,16 +63,24 @@ class CSRGraph:
         rowptr, col, eid = ops.csr_build(edge_index, n_dst)
         return cls(edge_index, n_src, n_dst, rowptr, col, eid)
 
-    def fold_sources(self, period: int) -> 'CSRGraph':
-        """Source rows that are ``period``-periodic copies (the reference tiles ``x_pl`` T times,
-        modules/qcnet_map_encoder.py:170, and K times, modules/qcnet_decoder.py:150-151) are gathered from one
-        copy: source index modulo ``period``.  ``edge_index`` keeps the reference numbering."""
-        return CSRGraph(self.edge_index, period, self.n_dst, self.rowptr, torch.remainder(self.col, period), self.eid)
-
     @classmethod
     def from_sorted(cls, edge_index: torch.Tensor, offset: torch.Tensor, n_src: int, n_dst: int) -> 'CSRGraph':
         """``edge_index`` already grouped by ascending destination with row pointer ``offset`` (int64)."""
         return cls(edge_index, n_src, n_dst, offset.to(torch.int32), edge_index[0].to(torch.int32), None)
+
+    def fold_sources(self, period: int) -> 'CSRGraph':
+        """Source rows that are ``period``-periodic copies (the reference tiles ``x_pl`` T times,
+        modules/qcnet_map_encoder.py:170, and K times, modules/qcnet_decoder.py:150-151) are gathered from one
+        copy: source index modulo ``period``.  ``edge_index`` keeps the reference numbering."""
+        return CSRGraph(self.edge_index, period, self.n_dst, self.rowptr, torch.remainder(self.col, period), self.eid,
+                        self.rep, self.layout)
+
+    def replicate(self, rep: int, layout: int, edge_index: Optional[torch.Tensor] = None) -> 'CSRGraph':
+        """The same edge list for ``rep`` mode copies of every destination row (see class docstring).
+        ``edge_index``: the reference's replicated COO list, kept for inspection / parity checks only."""
+        assert self.rep == 1 and layout in (ops.LAYOUT_MODE_MAJOR, ops.LAYOUT_AGENT_MAJOR)
+        return CSRGraph(edge_index if edge_index is not None else self.edge_index, self.n_src, self.n_dst * rep,
+                        self.rowptr, self.col, self.eid, rep, layout)
 
 
 def _ptr_from_batch(batch: Optional[torch.Tensor], n: int, device) -> torch.Tensor:

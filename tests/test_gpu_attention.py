@@ -117,3 +117,79 @@ def test_attention_layer_state_dict_keys_match_reference_names():
     assert layer.to_g.weight.shape == (128, 256) and layer.ff_mlp[0].weight.shape == (512, 128)
     assert layer.attn_prenorm_x_dst is layer.attn_prenorm_x_src
     assert len(list(layer.parameters())) == len(keys) - 2
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused positional form (qcn_attn_fused_f32) against the fp64 oracle fed with materialised kr / vr
+# ---------------------------------------------------------------------------------------------------------
+def _pos_weights(seed):
+    g = torch.Generator().manual_seed(seed)
+    w_kr = torch.randn(128, 128, generator=g) * 0.15
+    w_vr = torch.randn(128, 128, generator=g) * 0.15
+    b_vr = torch.randn(128, generator=g) * 0.1
+    gamma = 1.0 + torch.randn(128, generator=g) * 0.1
+    beta = torch.randn(128, generator=g) * 0.1
+    return w_kr, w_vr, b_vr, gamma, beta
+
+
+def _materialise(r, w_kr, w_vr, b_vr, gamma, beta):
+    rn = torch.nn.functional.layer_norm(r.double(), (128,), gamma.double(), beta.double(), 1e-5)
+    return (rn @ w_kr.double().t()).float(), (rn @ w_vr.double().t() + b_vr.double()).float()
+
+
+def _fused(q, k, v, r, graph, w_kr, w_vr, b_vr, gamma, beta, rep=1, layout=0):
+    wk = (w_kr * gamma[None]).to(DEV).contiguous()
+    wv = (w_vr * gamma[None]).to(DEV).contiguous()
+    bv = (w_vr @ beta + b_vr).to(DEV).contiguous()
+    rhat = ops.row_normalize(r.to(DEV))
+    return ops.attn_fused(q.to(DEV), k.to(DEV), v.to(DEV), rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, rep, layout)
+
+
+@pytest.mark.parametrize('n_src,n_dst,E,heavy,empty_from', [
+    (40, 30, 500, None, None),
+    (300, 257, 9000, 700, None),
+    (64, 100, 333, None, 60),
+    (5, 9, 0, None, None),
+    (700, 5000, 60000, None, None),          # more destinations than one pass of 256 workgroups x 16 waves
+])
+def test_attn_fused_vs_fp64_oracle(n_src, n_dst, E, heavy, empty_from):
+    ei = _graph(n_src, n_dst, E, 31, heavy, empty_from)
+    q, k, v, r = _feat(n_dst, 1, 1.5), _feat(n_src, 2, 1.5), _feat(n_src, 3), _feat(E, 4, 2.0) + 0.3
+    pw = _pos_weights(9)
+    kr, vr = _materialise(r, *pw)
+    want = c_attention(q, k, v, kr if E else None, vr if E else None, ei)
+    graph = CSRGraph.from_edge_index(ei.to(DEV), n_src, n_dst)
+    got = _fused(q, k, v, r, graph, *pw)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    if E:
+        assert rel_err(got, want) < 2e-5
+    deg = torch.bincount(ei[1], minlength=n_dst)
+    assert bool((got.cpu()[deg == 0] == 0).all())
+
+
+def test_row_normalize_matches_layer_norm():
+    x = _feat(1001, 5, 3.0) + 1.0
+    got = ops.row_normalize(x.to(DEV))
+    want = torch.nn.functional.layer_norm(x.double(), (128,), None, None, 1e-5)
+    assert rel_err(got, want) < 1e-6
+
+
+@pytest.mark.parametrize('layout', [1, 2])
+def test_attn_fused_mode_replication_equals_explicit_graph(layout):
+    """K mode queries per row sharing one edge list (qcnet_decoder.py:170,190-192) == the K-times replicated graph."""
+    K, n_rows, n_src, E = 6, 37, 50, 900
+    base = _graph(n_src, n_rows, E, 41, heavy=100, empty_from=30)
+    q, k, v, r = _feat(n_rows * K, 1, 1.5), _feat(n_src, 2, 1.5), _feat(n_src, 3), _feat(E, 4, 2.0)
+    pw = _pos_weights(10)
+    if layout == 1:      # mode-major destinations: node = m * n_rows + row; r.repeat(K, 1)
+        full = torch.cat([torch.stack([base[0], base[1] + m * n_rows]) for m in range(K)], dim=1)
+        r_full = r.repeat(K, 1)
+    else:                # agent-major destinations: node = row * K + m; r.repeat_interleave(K)
+        full = torch.stack([base[0].repeat_interleave(K), (base[1][:, None] * K + torch.arange(K)[None]).reshape(-1)])
+        r_full = r.repeat_interleave(K, dim=0)
+    kr, vr = _materialise(r_full, *pw)
+    want = c_attention(q, k, v, kr, vr, full)
+    g = CSRGraph.from_edge_index(base.to(DEV), n_src, n_rows).replicate(K, layout)
+    got = _fused(q, k, v, r, g, *pw, rep=K, layout=layout)
+    assert rel_err(got, want) < 2e-5
