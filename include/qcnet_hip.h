@@ -115,6 +115,21 @@ int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const flo
                        const float *wv, const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows,
                        int64_t num_edges, int rep, int layout, float *out, void *stream);
 
+/* A4 — the whole FourierEmbedding.forward (layers/fourier_embedding.py:49-67) in one launch:
+ *   x [n_rows, input_dim] (input_dim 0..4; NULL for 0), extra [ceil(n_rows / extra_div), 128] or NULL = the summed
+ *   categorical embeddings, row n of the output uses extra row n / extra_div (modules/qcnet_agent_encoder.py:109
+ *   repeats one type embedding per agent over T steps: extra_div = T); y [n_rows, 128].
+ *   normalize_out != 0 additionally applies (y - mean) / sqrt(var + 1e-5) per row, the layer-independent half of the
+ *   consuming AttentionLayers' attn_prenorm_r (layers/attention_layer.py:82).
+ *   pack: qcn_fourier_pack_floats(input_dim) floats, per input dim i
+ *     [freqs.weight[i] (64) | mlps.i.0.weight[:, :128]^T (k-major 128x128) | mlps.i.0.weight[:, 128] | mlps.i.0.bias |
+ *      mlps.i.1.weight | mlps.i.1.bias | mlps.i.3.weight^T (k-major) | mlps.i.3.bias]
+ *   followed by [to_out.0.weight | to_out.0.bias | to_out.2.weight^T (k-major) | to_out.2.bias].
+ *   hidden_dim = 128, num_freq_bands = 64 only. */
+size_t qcn_fourier_pack_floats(int input_dim);
+int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
+                          const float *pack, int64_t n_rows, int normalize_out, float *y, void *stream);
+
 /* K6 — y = (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine; the layer-independent half
  * of attn_prenorm_r, layers/attention_layer.py:63,82). */
 int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);

@@ -78,8 +78,9 @@ class QCNetAgentEncoder(nn.Module):
                            angle_between_2d_vectors(ctr_vector=head_vec_a, nbr_vector=motion),
                            torch.norm(vel, p=2, dim=-1),
                            angle_between_2d_vectors(ctr_vector=head_vec_a, nbr_vector=vel)], dim=-1)
-        type_emb = self.type_a_emb(agent['type'].long()).repeat_interleave(repeats=T, dim=0)
-        x_a = self.x_a_emb(continuous_inputs=x_a.view(-1, 4), categorical_embs=[type_emb])
+        # one type embedding per agent, shared by its T steps (reference: repeat_interleave(T), :109)
+        x_a = self.x_a_emb(continuous_inputs=x_a.view(-1, 4), categorical_embs=[self.type_a_emb(agent['type'].long())],
+                           categorical_repeat=T)
 
         # temporal relation, agent-major node id a * T + t: dst later than src by at most time_span steps
         pos_t, head_t = pos_a.reshape(-1, 2), head_a.reshape(-1)
@@ -87,9 +88,9 @@ class QCNetAgentEncoder(nn.Module):
         ei_t = ei_t[:, ei_t[1] > ei_t[0]]
         ei_t = ei_t[:, ei_t[1] - ei_t[0] <= self.time_span]
         g_t = CSRGraph.from_edge_index(ei_t, A * T, A * T, validate=False)
-        r_t = NormalizedEdgeFeatures.from_raw(self.r_t_emb(
+        r_t = NormalizedEdgeFeatures(self.r_t_emb(
             continuous_inputs=rel_geometry(pos_t, pos_t, head_t, head_t, ei_t, extra=ei_t[0] - ei_t[1]),
-            categorical_embs=None))
+            categorical_embs=None, normalized_output=True))
 
         # spatial relations, time-major node id t * A + a; one radius example per (time step, scenario)
         pos_s = pos_a.transpose(0, 1).reshape(-1, 2).contiguous()
@@ -104,14 +105,14 @@ class QCNetAgentEncoder(nn.Module):
 
         ei_pl2a, _ = ops.radius_pairs(pos_s, pos_pl_rep, self.pl2a_radius, ptr_s, ptr_pl, 300, mask_x=mask_s)
         g_pl2a = CSRGraph.from_edge_index(ei_pl2a, T * P, T * A, validate=False).fold_sources(P)
-        r_pl2a = NormalizedEdgeFeatures.from_raw(self.r_pl2a_emb(
-            continuous_inputs=rel_geometry(pos_pl_rep, pos_s, orient_pl_rep, head_s, ei_pl2a), categorical_embs=None))
+        r_pl2a = NormalizedEdgeFeatures(self.r_pl2a_emb(
+            continuous_inputs=rel_geometry(pos_pl_rep, pos_s, orient_pl_rep, head_s, ei_pl2a), categorical_embs=None, normalized_output=True))
 
         ei_a2a, off_a2a = ops.radius_pairs(pos_s, pos_s, self.a2a_radius, ptr_s, ptr_s, 300 + 1, drop_self=True,
                                            mask_x=mask_s, mask_y=mask_s, y_first=False)
         g_a2a = CSRGraph.from_sorted(ei_a2a, off_a2a, T * A, T * A)
-        r_a2a = NormalizedEdgeFeatures.from_raw(self.r_a2a_emb(
-            continuous_inputs=rel_geometry(pos_s, pos_s, head_s, head_s, ei_a2a), categorical_embs=None))
+        r_a2a = NormalizedEdgeFeatures(self.r_a2a_emb(
+            continuous_inputs=rel_geometry(pos_s, pos_s, head_s, head_s, ei_a2a), categorical_embs=None, normalized_output=True))
 
         x_pl = map_enc['x_pl'][:, 0]  # [P, C]; the T copies of reference :170 are identical
         for i in range(self.num_layers):

@@ -135,7 +135,7 @@ class QCNetDecoder(nn.Module):
         r_t2m = rel_geometry(pos_t, pos_m, head_t, head_m, ei_t2m_1, extra=(ei_t2m_1[0] % T) - T + 1)
         # One positional embedding / edge list per (step, agent) pair; the K mode queries of the agent share it
         # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
-        r_t2m = NormalizedEdgeFeatures.from_raw(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None))
+        r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=True))
         ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
         g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False).replicate(
             K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
@@ -145,8 +145,8 @@ class QCNetDecoder(nn.Module):
         ptr_a, ptr_p = node_ptr(data, 'agent', dev), node_ptr(data, 'map_polygon', dev)
         dst_ok = mask_dst[:, 0].contiguous()
         ei_pl2m_1, _ = ops.radius_pairs(pos_m, pos_pl, self.pl2m_radius, ptr_a, ptr_p, 300, mask_x=dst_ok)
-        r_pl2m = NormalizedEdgeFeatures.from_raw(self.r_pl2m_emb(
-            continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None))
+        r_pl2m = NormalizedEdgeFeatures(self.r_pl2m_emb(
+            continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=True))
         ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
         g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False).replicate(
             K, ops.LAYOUT_MODE_MAJOR, edge_index=ei_pl2m)
@@ -154,8 +154,8 @@ class QCNetDecoder(nn.Module):
         src_ok = mask_src[:, -1].contiguous()
         ei_a2m_1, off_a2m = ops.radius_pairs(pos_m, pos_m, self.a2m_radius, ptr_a, ptr_a, 300 + 1, drop_self=True,
                                              mask_x=src_ok, mask_y=dst_ok, y_first=False)
-        r_a2m = NormalizedEdgeFeatures.from_raw(self.r_a2m_emb(
-            continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None))
+        r_a2m = NormalizedEdgeFeatures(self.r_a2m_emb(
+            continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None, normalized_output=True))
         ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
         g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_MODE_MAJOR, edge_index=ei_a2m)
 

@@ -147,6 +147,28 @@ def row_normalize(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     return y
 
 
+def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor, extra: Optional[torch.Tensor] = None,
+                  extra_div: int = 1, normalize_out: bool = False, n_rows: Optional[int] = None) -> torch.Tensor:
+    """qcn_fourier_embed_f32: the whole FourierEmbedding forward; ``pack`` from ``pack_fourier_weights``."""
+    dev = pack.device
+    if input_dim > 0:
+        _require(x, 'continuous_inputs', torch.float32, dev, (None, input_dim))
+        n_rows = x.size(0)
+    elif n_rows is None:
+        n_rows = extra.size(0) * extra_div
+    need = _lib.lib().qcn_fourier_pack_floats(int(input_dim))
+    _require(pack, 'pack', torch.float32, dev, (need,))
+    if extra is not None:
+        _require(extra, 'categorical embedding sum', torch.float32, dev, ((n_rows + extra_div - 1) // extra_div, C))
+    elif input_dim == 0:
+        raise ValueError('Both continuous_inputs and categorical_embs are None')
+    y = torch.empty(n_rows, C, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_fourier_embed_f32(_ptr(x) if input_dim > 0 else None, int(input_dim), _ptr(extra),
+                                                int(extra_div), _ptr(pack), n_rows, int(bool(normalize_out)), _ptr(y),
+                                                _stream(dev)), 'qcn_fourier_embed_f32')
+    return y
+
+
 LAYOUT_PLAIN, LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR = 0, 1, 2
 
 
