@@ -130,6 +130,27 @@ size_t qcn_fourier_pack_floats(int input_dim);
 int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
                           const float *pack, int64_t n_rows, int normalize_out, float *y, void *stream);
 
+/* A2 node side (K5/K6 of SURVEY.md §2b fused) — xn = LayerNorm(x) (skipped when ln_weight == NULL);
+ * y_j = W_j xn + b_j for j < n_out <= 4 (the to_q / to_k / to_v / to_s projections of one AttentionLayer call,
+ * layers/attention_layer.py:74-79,115-117,108).  x, y_j, xn_out: [n_rows,128]; wt: n_out k-major matrices
+ * (wt[j][k][n] = W_j[n][k]); bias: [n_out,128] or NULL; xn_out may be NULL. */
+int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
+                      const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
+                      float *y3, float *xn_out, void *stream);
+
+/* A2 node side, after the propagate — gate/update, to_out, post-norm residual and the whole feed-forward block
+ * (layers/attention_layer.py:83-84,106-108,119,121-122):
+ *   g = sigmoid(to_g [agg, xn_dst]); u = agg + g (s_proj - agg); x1 = x_res + LN_post(to_out u);
+ *   out = x1 + LN_ffpost(ff_mlp.3 relu(ff_mlp.0 LN_ffpre(x1))).
+ * pack (qcn_attn_post_pack_floats() floats): 11 k-major 128x128 matrices in consumption order
+ *   [to_g.weight[:, :128]^T, to_g.weight[:, 128:]^T, to_out.weight^T, then for hb = 0..3:
+ *    ff_mlp.0.weight[128hb:128hb+128, :]^T, ff_mlp.3.weight[:, 128hb:128hb+128]^T]
+ * followed by [to_g.bias, to_out.bias, attn_postnorm.{weight,bias}, ff_prenorm.{weight,bias}, ff_mlp.0.bias (512),
+ *   ff_mlp.3.bias, ff_postnorm.{weight,bias}].  All tensors [n_rows,128] fp32. */
+size_t qcn_attn_post_pack_floats(void);
+int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
+                      const float *pack, int64_t n_rows, float *out, void *stream);
+
 /* K6 — y = (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine; the layer-independent half
  * of attn_prenorm_r, layers/attention_layer.py:63,82). */
 int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);

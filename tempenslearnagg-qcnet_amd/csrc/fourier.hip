@@ -12,19 +12,13 @@
 // once on the host) streamed from L2 through a double-buffered 32-k LDS chunk shared by the 4 waves, one barrier per
 // chunk, the next chunk's global loads in flight under the current chunk's 64 MFMAs per wave.
 // MFMA-bound: 2*128*(129+128) flops per row and input dim + 2*128*128 for to_out.
-#include "common.hip.h"
+#include "mfma_tile.hip.h"
 
 namespace {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
+using namespace qcn_tile;
 
-constexpr int kC = 128;
 constexpr int kF = 64;
-constexpr int kRowsPerWave = 32;
-constexpr int kRowsPerBlock = 128;
-constexpr int kChunkK = 32;
-constexpr int kPad = 33;
-
 // packed parameter layout (floats); see ops.pack_fourier_weights
 constexpr int kOffFreq = 0;                       // [64]
 constexpr int kOffW1t = 64;                       // [128 k][128 n]
@@ -36,106 +30,6 @@ constexpr int kOffW2t = kOffBe1 + kC;             // [128 k][128 n]
 constexpr int kOffB2 = kOffW2t + kC * kC;
 constexpr int kDimStride = kOffB2 + kC;
 constexpr int kOutG = 0, kOutBe = kC, kOutWt = 2 * kC, kOutB = 2 * kC + kC * kC, kOutStride = 3 * kC + kC * kC;
-
-template <int CTRL>
-__device__ __forceinline__ float dpp_mov(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
-}
-
-// sum over the 32 lanes of a wave half
-__device__ __forceinline__ float half_sum(float v)
-{
-    v += dpp_mov<0xB1>(v);    // xor 1
-    v += dpp_mov<0x4E>(v);    // xor 2
-    v += dpp_mov<0x141>(v);   // row_half_mirror (xor 7)
-    v += dpp_mov<0x128>(v);   // row_ror:8
-    v += __shfl_xor(v, 16);
-    return v;
-}
-
-struct Smem {
-    float a[4][kC][kPad];          // per-wave A tile, k-major
-    float w[2][kChunkK][kC];       // weight chunk double buffer
-    float x[4][4][kRowsPerWave];   // raw inputs of the wave's rows
-};
-
-// accumulator element (tile t, reg r) of a lane is  row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5),  col = 32 t + (lane & 31)
-__device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
-
-// LayerNorm (+ optional affine, + optional ReLU) over complete rows held in the accumulators
-template <bool AFFINE, bool RELU>
-__device__ __forceinline__ void row_layer_norm(f32x16 (&acc)[4], const float *__restrict__ gamma,
-                                               const float *__restrict__ beta, int lane, float eps)
-{
-    float g[4], b[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        g[t] = AFFINE ? gamma[32 * t + (lane & 31)] : 1.f;
-        b[t] = AFFINE ? beta[32 * t + (lane & 31)] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float mean = half_sum(acc[0][r] + acc[1][r] + acc[2][r] + acc[3][r]) * (1.0f / kC);
-        float d[4], sq = 0.f;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { d[t] = acc[t][r] - mean; sq = fmaf(d[t], d[t], sq); }
-        const float rstd = rsqrtf(half_sum(sq) * (1.0f / kC) + eps);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            float v = AFFINE ? fmaf(d[t] * rstd, g[t], b[t]) : d[t] * rstd;
-            acc[t][r] = RELU ? fmaxf(v, 0.f) : v;
-        }
-    }
-}
-
-__device__ __forceinline__ void acc_to_tile(const f32x16 (&acc)[4], float (&tile)[kC][kPad], int lane)
-{
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) tile[32 * t + (lane & 31)][acc_row(r, lane)] = acc[t][r];
-}
-
-struct Stream {            // weight chunk stream state (all threads of the workgroup)
-    float4 pre[4];         // prefetched chunk: 32 k x 128 n floats = 16 KiB / 256 threads = 4 float4 each
-    int chunk;             // index of the chunk held in `pre`
-};
-
-__device__ __forceinline__ void prefetch_chunk(Stream &s, const float *__restrict__ wt, int tid)
-{
-    const float4 *src = reinterpret_cast<const float4 *>(wt);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s.pre[i] = src[i * 256 + tid];
-}
-
-// acc[0..3] += A(32 x 128, wave tile) * Wt(128 x 128) with Wt streamed in four 32-k chunks.  `next` = the first chunk of
-// the following GEMM (or nullptr): its loads are issued before the last chunk's MFMAs.
-__device__ __forceinline__ void gemm_pass(f32x16 (&acc)[4], Smem &sm, Stream &s, const float *__restrict__ wt,
-                                          const float *__restrict__ next, int wave, int lane, int tid)
-{
-#pragma unroll 1
-    for (int c = 0; c < kC / kChunkK; ++c) {
-        float (&buf)[kChunkK][kC] = sm.w[s.chunk & 1];
-        float4 *dst = reinterpret_cast<float4 *>(&buf[0][0]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dst[i * 256 + tid] = s.pre[i];
-        __syncthreads();
-        const float *nxt = (c + 1 < kC / kChunkK) ? wt + (c + 1) * kChunkK * kC : next;
-        if (nxt != nullptr) prefetch_chunk(s, nxt, tid);
-        s.chunk++;
-        const int kbase = c * kChunkK;
-#pragma unroll
-        for (int ks = 0; ks < kChunkK / 2; ++ks) {
-            const float av = sm.a[wave][kbase + 2 * ks + (lane >> 5)][lane & 31];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const float bv = buf[2 * ks + (lane >> 5)][32 * t + (lane & 31)];
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
-            }
-        }
-    }
-}
 
 template <int IN>
 __global__ __launch_bounds__(256) void fourier_kernel(const float *__restrict__ x, const float *__restrict__ extra,

@@ -78,23 +78,43 @@ class AttentionLayer(nn.Module):
         self.ff_prenorm = nn.LayerNorm(hidden_dim)
         self.ff_postnorm = nn.LayerNorm(hidden_dim)
         self.apply(weight_init)
-        self._fold_key = None
-        self._fold = None
+        self._pack_key = None
+        self._packs = None
 
-    def _folded_pos_weights(self):
-        """wk = to_k_r.weight * gamma, wv = to_v_r.weight * gamma, bv = to_v_r.weight @ beta + to_v_r.bias with
-        (gamma, beta) the affine of attn_prenorm_r: what qcn_attn_fused_f32 consumes.  Cached per parameter version."""
-        prm = (self.to_k_r.weight, self.to_v_r.weight, self.to_v_r.bias, self.attn_prenorm_r.weight,
-               self.attn_prenorm_r.bias)
-        key = tuple((p.data_ptr(), p._version) for p in prm)
-        if key != self._fold_key:
-            with torch.no_grad():
+    def _kernel_packs(self):
+        """All parameters in the layouts the kernels consume (include/qcnet_hip.h), cached per parameter version:
+        ``pre_*``: k-major projection stacks for qcn_ln_linear_f32; ``post``: qcn_attn_post_f32 pack;
+        ``pos``: (wk, wv, bv) for qcn_attn_fused_f32 with the attn_prenorm_r affine folded in
+        (wk = to_k_r.weight * gamma, wv = to_v_r.weight * gamma, bv = to_v_r.weight @ beta + to_v_r.bias)."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if key == self._pack_key:
+            return self._packs
+        C = ops.C
+        with torch.no_grad():
+            zero = torch.zeros(C, device=self.to_q.weight.device)
+            t = lambda lin: lin.weight.t().contiguous()
+            packs = {}
+            packs['pre_src'] = (torch.stack([t(self.to_k), t(self.to_v)]).contiguous(),
+                                torch.stack([zero, self.to_v.bias]).contiguous())
+            packs['pre_dst'] = (torch.stack([t(self.to_q), t(self.to_s)]).contiguous(),
+                                torch.stack([self.to_q.bias, self.to_s.bias]).contiguous())
+            packs['pre_all'] = (torch.stack([t(self.to_q), t(self.to_k), t(self.to_v), t(self.to_s)]).contiguous(),
+                                torch.stack([self.to_q.bias, zero, self.to_v.bias, self.to_s.bias]).contiguous())
+            mats = [self.to_g.weight[:, :C].t(), self.to_g.weight[:, C:].t(), self.to_out.weight.t()]
+            w1, w2 = self.ff_mlp[0], self.ff_mlp[3]
+            for hb in range(4):
+                mats += [w1.weight[hb * C:(hb + 1) * C, :].t(), w2.weight[:, hb * C:(hb + 1) * C].t()]
+            vecs = [self.to_g.bias, self.to_out.bias, self.attn_postnorm.weight, self.attn_postnorm.bias,
+                    self.ff_prenorm.weight, self.ff_prenorm.bias, w1.bias, w2.bias, self.ff_postnorm.weight,
+                    self.ff_postnorm.bias]
+            packs['post'] = torch.cat([m.reshape(-1) for m in mats] + [v.reshape(-1) for v in vecs]).float().contiguous()
+            if self.has_pos_emb:
                 gamma, beta = self.attn_prenorm_r.weight, self.attn_prenorm_r.bias
-                wk = (self.to_k_r.weight * gamma.unsqueeze(0)).contiguous()
-                wv = (self.to_v_r.weight * gamma.unsqueeze(0)).contiguous()
-                bv = (self.to_v_r.weight @ beta + self.to_v_r.bias).contiguous()
-            self._fold, self._fold_key = (wk, wv, bv), key
-        return self._fold
+                packs['pos'] = ((self.to_k_r.weight * gamma.unsqueeze(0)).contiguous(),
+                                (self.to_v_r.weight * gamma.unsqueeze(0)).contiguous(),
+                                (self.to_v_r.weight @ beta + self.to_v_r.bias).contiguous())
+        self._packs, self._pack_key = packs, key
+        return packs
 
     def forward(self,
                 x: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]],
@@ -105,20 +125,21 @@ class AttentionLayer(nn.Module):
         row-normalised (``NormalizedEdgeFeatures``)."""
         if self.training and self.dropout > 0:
             raise RuntimeError('AttentionLayer is inference-only: call .eval() (dropout is not implemented)')
-        if isinstance(x, torch.Tensor):
-            x_src = x_dst = self.attn_prenorm_x_src(x)
+        packs = self._kernel_packs()
+        single = isinstance(x, torch.Tensor)   # one node set: source and destination share LN(x) (reference :74-75)
+        if single:
+            x_res = x.contiguous()
+            n_src = n_dst = x_res.size(0)
         else:
-            x_src, x_dst = x
-            x_src = self.attn_prenorm_x_src(x_src)
-            x_dst = self.attn_prenorm_x_dst(x_dst)
-            x = x[1]
+            x_src, x_res = x[0].contiguous(), x[1].contiguous()
+            n_src, n_dst = x_src.size(0), x_res.size(0)
         if isinstance(edge_index, CSRGraph):
             graph = edge_index
-            if graph.n_src != x_src.size(0) or graph.n_dst != x_dst.size(0):
+            if graph.n_src != n_src or graph.n_dst != n_dst:
                 raise ValueError('CSRGraph is %d -> %d nodes but x has %d -> %d rows'
-                                 % (graph.n_src, graph.n_dst, x_src.size(0), x_dst.size(0)))
+                                 % (graph.n_src, graph.n_dst, n_src, n_dst))
         else:
-            graph = CSRGraph.from_edge_index(edge_index, x_src.size(0), x_dst.size(0))
+            graph = CSRGraph.from_edge_index(edge_index, n_src, n_dst)
         if self.has_pos_emb and r is not None:
             if not isinstance(r, NormalizedEdgeFeatures):
                 r = NormalizedEdgeFeatures.from_raw(r, self.attn_prenorm_r.eps)
@@ -126,22 +147,21 @@ class AttentionLayer(nn.Module):
                 raise ValueError('r has %d rows for %d edges' % (r.rhat.size(0), graph.num_base_edges))
         else:
             r = None
-        x = x + self.attn_postnorm(self._attn_block(x_src, x_dst, r, graph))
-        x = x + self.ff_postnorm(self.ff_mlp(self.ff_prenorm(x)))
-        return x
-
-    def _attn_block(self, x_src: torch.Tensor, x_dst: torch.Tensor, r: Optional[NormalizedEdgeFeatures],
-                    graph: CSRGraph) -> torch.Tensor:
-        q = self.to_q(x_dst)
-        k = self.to_k(x_src)
-        v = self.to_v(x_src)
+        # pre: LayerNorm + q/k/v/s projections (one or two launches)
+        if not single:
+            ln_s, ln_d = self.attn_prenorm_x_src, self.attn_prenorm_x_dst
+            (k, v), _ = ops.ln_linear(x_src, ln_s.weight, ln_s.bias, *packs['pre_src'])
+            (q, s), xn_dst = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'], want_xn=True)
+        else:
+            ln = self.attn_prenorm_x_src
+            (q, k, v, s), xn_dst = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_all'], want_xn=True)
+        # propagate: gather + segment softmax + weighted scatter-add (one launch)
         if r is not None:
-            wk, wv, bv = self._folded_pos_weights()
-            agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep,
-                                 graph.layout)
+            wk, wv, bv = packs['pos']
+            agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep, graph.layout)
         else:
             if graph.rep != 1:
                 raise ValueError('mode-replicated graphs need a positional embedding')
             agg = ops.attn_fwd(q, k, v, None, None, graph.rowptr, graph.col, graph.eid)
-        g = torch.sigmoid(self.to_g(torch.cat([agg, x_dst], dim=-1)))
-        return self.to_out(agg + g * (self.to_s(x_dst) - agg))
+        # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)
+        return ops.attn_post(agg, xn_dst, s, x_res, packs['post'])

@@ -169,6 +169,44 @@ def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor,
     return y
 
 
+def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], wt: torch.Tensor,
+              bias: Optional[torch.Tensor], want_xn: bool = False):
+    """qcn_ln_linear_f32: ([y_0 .. y_{n_out-1}], xn or None) with y_j = W_j LayerNorm(x) + b_j; ``wt`` is the stack
+    of k-major (transposed) weights [n_out, 128, 128], ``bias`` [n_out, 128] or None."""
+    dev = x.device
+    n = x.size(0)
+    n_out = wt.size(0)
+    _require(x, 'x', torch.float32, dev, (n, C))
+    _require(wt, 'wt', torch.float32, dev, (n_out, C, C))
+    if not 1 <= n_out <= 4:
+        raise ValueError('n_out must be 1..4')
+    if bias is not None:
+        _require(bias, 'bias', torch.float32, dev, (n_out, C))
+    if ln_weight is not None:
+        _require(ln_weight, 'ln_weight', torch.float32, dev, (C,))
+        _require(ln_bias, 'ln_bias', torch.float32, dev, (C,))
+    ys = [torch.empty(n, C, dtype=torch.float32, device=dev) for _ in range(n_out)]
+    xn = torch.empty(n, C, dtype=torch.float32, device=dev) if want_xn else None
+    yp = [_ptr(y) for y in ys] + [None] * (4 - n_out)
+    _lib.check(_lib.lib().qcn_ln_linear_f32(_ptr(x), n, _ptr(ln_weight), _ptr(ln_bias), _ptr(wt), _ptr(bias), n_out,
+                                            yp[0], yp[1], yp[2], yp[3], _ptr(xn), _stream(dev)), 'qcn_ln_linear_f32')
+    return ys, xn
+
+
+def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_res: torch.Tensor,
+              pack: torch.Tensor) -> torch.Tensor:
+    """qcn_attn_post_f32: gate/update + to_out + post-norm residual + feed-forward block of one AttentionLayer."""
+    dev = agg.device
+    n = agg.size(0)
+    for name, t in (('agg', agg), ('xn_dst', xn_dst), ('s_proj', s_proj), ('x_res', x_res)):
+        _require(t, name, torch.float32, dev, (n, C))
+    _require(pack, 'pack', torch.float32, dev, (_lib.lib().qcn_attn_post_pack_floats(),))
+    out = torch.empty(n, C, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_attn_post_f32(_ptr(agg), _ptr(xn_dst), _ptr(s_proj), _ptr(x_res), _ptr(pack), n, _ptr(out),
+                                            _stream(dev)), 'qcn_attn_post_f32')
+    return out
+
+
 LAYOUT_PLAIN, LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR = 0, 1, 2
 
 
