@@ -109,11 +109,14 @@ int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, const float
  *   layout 0: n_rows == n_dst, rep == 1, destination node = CSR row;
  *   layout 1: destination node = mode * n_rows + row   (mode-major, pl2m / a2m);
  *   layout 2: destination node = row * rep + mode      (agent-major, t2m);   n_dst == n_rows * rep.
- * rowptr [n_rows+1], col / eid [E_base] as in qcn_csr_build (eid NULL: rhat rows are in CSR order). */
+ * rowptr [n_rows+1], col / eid [E_base] as in qcn_csr_build (eid NULL: rhat rows are in CSR order).
+ * rowptr entries are offsets into col / eid and need not start at 0: a window of consecutive rows of a larger graph is
+ * passed as a pointer into that graph's rowptr (the sliding frames of predictors/temp_ens_learn_agg.py:197 are such
+ * windows of one absolute-time graph); col_shift is subtracted from every col entry to re-base source ids. */
 int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const float *rhat,
                        const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *wk,
                        const float *wv, const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows,
-                       int64_t num_edges, int rep, int layout, float *out, void *stream);
+                       int64_t num_edges, int rep, int layout, int64_t col_shift, float *out, void *stream);
 
 /* A4 — the whole FourierEmbedding.forward (layers/fourier_embedding.py:49-67) in one launch:
  *   x [n_rows, input_dim] (input_dim 0..4; NULL for 0), extra [ceil(n_rows / extra_div), 128] or NULL = the summed

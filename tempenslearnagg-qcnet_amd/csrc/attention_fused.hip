@@ -82,6 +82,7 @@ struct FusedArgs {
     float *out;
     int64_t n_dst;
     int n_rows, rep, layout;       // layout 0: node = row; 1: node = mode*n_rows + row; 2: node = row*rep + mode
+    int col_shift;                 // source row = col[slot] - col_shift (window views of an absolute-time graph)
 };
 
 template <bool HAS_EID>
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
 #pragma unroll
                 for (int t = 0; t < kUnroll; ++t) {
                     const int jj = min(j + t, end - 1);           // clamp, mask below (no per-load branches)
-                    const int src = a.col[jj];
+                    const int src = a.col[jj] - a.col_shift;
                     const int e = HAS_EID ? a.eid[jj] : jj;
                     kk[t] = ld2(a.k, src, lane);
                     vv[t] = ld2(a.v, src, lane);
@@ -272,7 +273,7 @@ extern "C" int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, f
 extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const float *rhat,
                                   const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *wk,
                                   const float *wv, const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows,
-                                  int64_t num_edges, int rep, int layout, float *out, void *stream)
+                                  int64_t num_edges, int rep, int layout, int64_t col_shift, float *out, void *stream)
 {
     if (n_dst < 0 || n_src < 0 || n_rows < 0 || num_edges < 0 || rep < 1) return QCN_ERR_INVALID_ARGUMENT;
     if (layout < 0 || layout > 2) return QCN_ERR_INVALID_ARGUMENT;
@@ -282,7 +283,8 @@ extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v
     if (num_edges > 0 && (!k || !v || !col || !rhat)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_dst >= ((int64_t)1 << 31) || n_src >= ((int64_t)1 << 31) || num_edges >= ((int64_t)1 << 31))
         return QCN_ERR_UNSUPPORTED;
-    FusedArgs args{q, k, v, rhat, rowptr, col, eid, wk, wv, bv, out, n_dst, (int)n_rows, rep, layout};
+    if (col_shift < 0 || col_shift >= ((int64_t)1 << 31)) return QCN_ERR_INVALID_ARGUMENT;
+    FusedArgs args{q, k, v, rhat, rowptr, col, eid, wk, wv, bv, out, n_dst, (int)n_rows, rep, layout, (int)col_shift};
     // one workgroup per CU (144 KiB of LDS); every workgroup gets a contiguous chunk of >= 16 destinations
     int64_t grid = (n_dst + kWaves - 1) / kWaves;
     if (grid > 256) grid = 256;

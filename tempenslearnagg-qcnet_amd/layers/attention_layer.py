@@ -143,8 +143,8 @@ class AttentionLayer(nn.Module):
         if self.has_pos_emb and r is not None:
             if not isinstance(r, NormalizedEdgeFeatures):
                 r = NormalizedEdgeFeatures.from_raw(r, self.attn_prenorm_r.eps)
-            if r.rhat.size(0) != graph.num_base_edges:
-                raise ValueError('r has %d rows for %d edges' % (r.rhat.size(0), graph.num_base_edges))
+            if r.rhat.size(0) != graph.num_feature_rows:
+                raise ValueError('r has %d rows for %d edges' % (r.rhat.size(0), graph.num_feature_rows))
         else:
             r = None
         # pre: LayerNorm + q/k/v/s projections (one or two launches)
@@ -158,10 +158,11 @@ class AttentionLayer(nn.Module):
         # propagate: gather + segment softmax + weighted scatter-add (one launch)
         if r is not None:
             wk, wv, bv = packs['pos']
-            agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep, graph.layout)
+            agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep, graph.layout,
+                                 graph.col_shift)
         else:
-            if graph.rep != 1:
-                raise ValueError('mode-replicated graphs need a positional embedding')
+            if graph.rep != 1 or graph.col_shift != 0:
+                raise ValueError('mode-replicated / windowed graphs need a positional embedding')
             agg = ops.attn_fwd(q, k, v, None, None, graph.rowptr, graph.col, graph.eid)
         # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)
         return ops.attn_post(agg, xn_dst, s, x_res, packs['post'])

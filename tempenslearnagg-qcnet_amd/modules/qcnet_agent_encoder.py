@@ -59,62 +59,65 @@ class QCNetAgentEncoder(nn.Module):
         self.a2a_attn_layers = nn.ModuleList([AttentionLayer(bipartite=False, **layer) for _ in range(num_layers)])
         self.apply(weight_init)
 
-    def forward(self, data, map_enc: Mapping[str, torch.Tensor], time_shift: int) -> Dict[str, torch.Tensor]:
-        T, C, ts = self.num_historical_steps, self.hidden_dim, int(time_shift)
-        agent = data['agent']
-        A = int(agent['num_nodes'])
-        P = int(data['map_polygon']['num_nodes'])
-        mask = agent['valid_mask'][:, ts:T + ts].contiguous()
-        pos_a = agent['position'][:, ts:T + ts, :2].contiguous()
+    # ------------------------------------------------------------------------------------------------------------
+    # shared pieces
+    # ------------------------------------------------------------------------------------------------------------
+    def _agent_features(self, pos: torch.Tensor, prev: torch.Tensor, head: torch.Tensor, vel: torch.Tensor) -> torch.Tensor:
+        """x_a inputs (reference :116-120): [|motion|, angle(heading, motion), |velocity|, angle(heading, velocity)]."""
+        motion = pos - prev
+        head_vec = torch.stack([head.cos(), head.sin()], dim=-1)
+        return torch.stack([torch.norm(motion, p=2, dim=-1),
+                            angle_between_2d_vectors(ctr_vector=head_vec, nbr_vector=motion),
+                            torch.norm(vel, p=2, dim=-1),
+                            angle_between_2d_vectors(ctr_vector=head_vec, nbr_vector=vel)], dim=-1)
+
+    def _temporal_edges(self, mask: torch.Tensor) -> torch.Tensor:
+        """dst later than src by at most time_span steps, both valid (reference :129-132); node id a * n + t."""
+        ei = dense_to_sparse(mask.unsqueeze(2) & mask.unsqueeze(1))[0]
+        ei = ei[:, ei[1] > ei[0]]
+        return ei[:, ei[1] - ei[0] <= self.time_span]
+
+    def _step_ptrs(self, data, n_steps: int, dev):
+        """Example boundaries for the spatial searches: one example per (time step, scenario), time-major node ids
+        (reference batch ids b + B * t, :148-157)."""
+        A, P = int(data['agent']['num_nodes']), int(data['map_polygon']['num_nodes'])
+        steps = torch.arange(n_steps, device=dev, dtype=torch.int64).unsqueeze(1)
+        ptr_a, ptr_p = node_ptr(data, 'agent', dev), node_ptr(data, 'map_polygon', dev)
+        ptr_s = torch.cat([(steps * A + ptr_a[:-1]).reshape(-1), ptr_a.new_tensor([n_steps * A])])
+        ptr_pl = torch.cat([(steps * P + ptr_p[:-1]).reshape(-1), ptr_p.new_tensor([n_steps * P])])
+        return ptr_s, ptr_pl
+
+    def _spatial_relations(self, data, pos_a, head_a, mask, n_steps: int):
+        """Polygon→agent and agent→agent relations over ``n_steps`` time steps (time-major node ids t * A + a):
+        edge lists from the HIP radius kernel with the validity filters of reference :160,170 fused in,
+        destination-sorted CSR, row-normalised positional embeddings."""
+        A, P = int(data['agent']['num_nodes']), int(data['map_polygon']['num_nodes'])
         dev = pos_a.device
-        motion = torch.cat([pos_a.new_zeros(A, 1, 2), pos_a[:, 1:] - pos_a[:, :-1]], dim=1)
-        head_a = agent['heading'][:, ts:T + ts].contiguous()
-        head_vec_a = torch.stack([head_a.cos(), head_a.sin()], dim=-1)
         pos_pl = data['map_polygon']['position'][:, :2].contiguous()
         orient_pl = data['map_polygon']['orientation'].contiguous()
-        vel = agent['velocity'][:, ts:T + ts, :2].contiguous()
-
-        x_a = torch.stack([torch.norm(motion, p=2, dim=-1),
-                           angle_between_2d_vectors(ctr_vector=head_vec_a, nbr_vector=motion),
-                           torch.norm(vel, p=2, dim=-1),
-                           angle_between_2d_vectors(ctr_vector=head_vec_a, nbr_vector=vel)], dim=-1)
-        # one type embedding per agent, shared by its T steps (reference: repeat_interleave(T), :109)
-        x_a = self.x_a_emb(continuous_inputs=x_a.view(-1, 4), categorical_embs=[self.type_a_emb(agent['type'].long())],
-                           categorical_repeat=T)
-
-        # temporal relation, agent-major node id a * T + t: dst later than src by at most time_span steps
-        pos_t, head_t = pos_a.reshape(-1, 2), head_a.reshape(-1)
-        ei_t = dense_to_sparse(mask.unsqueeze(2) & mask.unsqueeze(1))[0]
-        ei_t = ei_t[:, ei_t[1] > ei_t[0]]
-        ei_t = ei_t[:, ei_t[1] - ei_t[0] <= self.time_span]
-        g_t = CSRGraph.from_edge_index(ei_t, A * T, A * T, validate=False)
-        r_t = NormalizedEdgeFeatures(self.r_t_emb(
-            continuous_inputs=rel_geometry(pos_t, pos_t, head_t, head_t, ei_t, extra=ei_t[0] - ei_t[1]),
-            categorical_embs=None, normalized_output=True))
-
-        # spatial relations, time-major node id t * A + a; one radius example per (time step, scenario)
         pos_s = pos_a.transpose(0, 1).reshape(-1, 2).contiguous()
         head_s = head_a.transpose(0, 1).reshape(-1)
         mask_s = mask.transpose(0, 1).reshape(-1).contiguous()
-        pos_pl_rep = pos_pl.repeat(T, 1)
-        orient_pl_rep = orient_pl.repeat(T)
-        steps = torch.arange(T, device=dev, dtype=torch.int64).unsqueeze(1)
-        ptr_a, ptr_p = node_ptr(data, 'agent', dev), node_ptr(data, 'map_polygon', dev)
-        ptr_s = torch.cat([(steps * A + ptr_a[:-1]).reshape(-1), ptr_a.new_tensor([T * A])])
-        ptr_pl = torch.cat([(steps * P + ptr_p[:-1]).reshape(-1), ptr_p.new_tensor([T * P])])
+        pos_pl_rep = pos_pl.repeat(n_steps, 1)
+        orient_pl_rep = orient_pl.repeat(n_steps)
+        ptr_s, ptr_pl = self._step_ptrs(data, n_steps, dev)
 
-        ei_pl2a, _ = ops.radius_pairs(pos_s, pos_pl_rep, self.pl2a_radius, ptr_s, ptr_pl, 300, mask_x=mask_s)
-        g_pl2a = CSRGraph.from_edge_index(ei_pl2a, T * P, T * A, validate=False).fold_sources(P)
+        ei_pl2a, off_pl2a = ops.radius_pairs(pos_s, pos_pl_rep, self.pl2a_radius, ptr_s, ptr_pl, 300, mask_x=mask_s)
+        g_pl2a = CSRGraph.from_edge_index(ei_pl2a, n_steps * P, n_steps * A, validate=False).fold_sources(P)
         r_pl2a = NormalizedEdgeFeatures(self.r_pl2a_emb(
-            continuous_inputs=rel_geometry(pos_pl_rep, pos_s, orient_pl_rep, head_s, ei_pl2a), categorical_embs=None, normalized_output=True))
+            continuous_inputs=rel_geometry(pos_pl_rep, pos_s, orient_pl_rep, head_s, ei_pl2a), categorical_embs=None,
+            normalized_output=True))
 
         ei_a2a, off_a2a = ops.radius_pairs(pos_s, pos_s, self.a2a_radius, ptr_s, ptr_s, 300 + 1, drop_self=True,
                                            mask_x=mask_s, mask_y=mask_s, y_first=False)
-        g_a2a = CSRGraph.from_sorted(ei_a2a, off_a2a, T * A, T * A)
+        g_a2a = CSRGraph.from_sorted(ei_a2a, off_a2a, n_steps * A, n_steps * A)
         r_a2a = NormalizedEdgeFeatures(self.r_a2a_emb(
-            continuous_inputs=rel_geometry(pos_s, pos_s, head_s, head_s, ei_a2a), categorical_embs=None, normalized_output=True))
+            continuous_inputs=rel_geometry(pos_s, pos_s, head_s, head_s, ei_a2a), categorical_embs=None,
+            normalized_output=True))
+        return dict(g_pl2a=g_pl2a, r_pl2a=r_pl2a, off_pl2a=off_pl2a, g_a2a=g_a2a, r_a2a=r_a2a, off_a2a=off_a2a)
 
-        x_pl = map_enc['x_pl'][:, 0]  # [P, C]; the T copies of reference :170 are identical
+    def _layers(self, x_a, x_pl, g_t, r_t, g_pl2a, r_pl2a, g_a2a, r_a2a) -> torch.Tensor:
+        T, C = self.num_historical_steps, self.hidden_dim
         for i in range(self.num_layers):
             x_a = x_a.reshape(-1, C)
             x_a = self.t_attn_layers[i](x_a, r_t, g_t)
@@ -122,4 +125,105 @@ class QCNetAgentEncoder(nn.Module):
             x_a = self.pl2a_attn_layers[i]((x_pl, x_a), r_pl2a, g_pl2a)
             x_a = self.a2a_attn_layers[i](x_a, r_a2a, g_a2a)
             x_a = x_a.reshape(T, -1, C).transpose(0, 1)
-        return {'x_a': x_a, 'edge_index_t': ei_t, 'edge_index_pl2a': ei_pl2a, 'edge_index_a2a': ei_a2a}
+        return x_a
+
+    # ------------------------------------------------------------------------------------------------------------
+    # sliding-window reuse: everything that depends on ABSOLUTE time only, computed once for all frames
+    # ------------------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def precompute(self, data, first_shift: int, last_shift: int) -> Dict[str, object]:
+        """The sliding loop (predictors/temp_ens_learn_agg.py:197) encodes windows [ts, ts + T) for consecutive
+        ``ts``.  A node (agent a, absolute step tau) has the same input features, the same spatial neighbours and the
+        same relative geometry in every window that contains it (only the very first step of a window differs: its
+        motion vector is zero, reference :99), so the Fourier embeddings, the radius searches and the CSR of the
+        spatial relations are computed once over tau in [first_shift, last_shift + T) and every frame takes views."""
+        T, C = self.num_historical_steps, self.hidden_dim
+        s0, n_frames = int(first_shift), int(last_shift) - int(first_shift) + 1
+        n_abs = T + n_frames - 1
+        agent = data['agent']
+        A = int(agent['num_nodes'])
+        mask = agent['valid_mask'][:, s0:s0 + n_abs].contiguous()
+        pos = agent['position'][:, s0:s0 + n_abs, :2].contiguous()
+        head = agent['heading'][:, s0:s0 + n_abs].contiguous()
+        vel = agent['velocity'][:, s0:s0 + n_abs, :2].contiguous()
+        if s0 >= 1:
+            prev = agent['position'][:, s0 - 1:s0 + n_abs - 1, :2]
+        else:
+            prev = torch.cat([pos[:, :1], pos[:, :-1]], dim=1)
+        type_emb = [self.type_a_emb(agent['type'].long())]
+        x_main = self.x_a_emb(continuous_inputs=self._agent_features(pos, prev, head, vel).view(-1, 4),
+                              categorical_embs=type_emb, categorical_repeat=n_abs).view(A, n_abs, C)
+        pf, hf, vf = pos[:, :n_frames], head[:, :n_frames], vel[:, :n_frames]
+        x_first = self.x_a_emb(continuous_inputs=self._agent_features(pf, pf, hf, vf).reshape(-1, 4),
+                               categorical_embs=type_emb, categorical_repeat=n_frames).view(A, n_frames, C)
+
+        ei_t = self._temporal_edges(mask)                                    # node id a * n_abs + u
+        pos_t, head_t = pos.reshape(-1, 2), head.reshape(-1)
+        r_t = NormalizedEdgeFeatures(self.r_t_emb(
+            continuous_inputs=rel_geometry(pos_t, pos_t, head_t, head_t, ei_t, extra=ei_t[0] - ei_t[1]),
+            categorical_embs=None, normalized_output=True))
+        agent_of_edge = torch.div(ei_t[0], n_abs, rounding_mode='floor')
+        cache = dict(first_shift=s0, n_frames=n_frames, n_abs=n_abs, x_main=x_main, x_first=x_first, r_t=r_t,
+                     t_agent=agent_of_edge, t_src=ei_t[0] - agent_of_edge * n_abs, t_dst=ei_t[1] - agent_of_edge * n_abs)
+        cache.update(self._spatial_relations(data, pos, head, mask, n_abs))
+        return cache
+
+    def _forward_cached(self, data, map_enc, time_shift: int, cache, return_edge_index: bool) -> Dict[str, torch.Tensor]:
+        T = self.num_historical_steps
+        A, P = int(data['agent']['num_nodes']), int(data['map_polygon']['num_nodes'])
+        u0 = int(time_shift) - cache['first_shift']
+        if not 0 <= u0 < cache['n_frames']:
+            raise ValueError('time_shift %d is outside the precomputed range' % time_shift)
+        x_a = torch.cat([cache['x_first'][:, u0:u0 + 1], cache['x_main'][:, u0 + 1:u0 + T]], dim=1)
+
+        keep = (cache['t_src'] >= u0) & (cache['t_dst'] < u0 + T)
+        sel = keep.nonzero(as_tuple=True)[0]
+        base = cache['t_agent'][sel] * T - u0
+        ei_t = torch.stack([base + cache['t_src'][sel], base + cache['t_dst'][sel]], dim=0)
+        g_t = CSRGraph.from_edge_index(ei_t, A * T, A * T, validate=False)
+        g_t.eid = sel.to(torch.int32)[g_t.eid.long()]
+        g_t.num_feature_rows = cache['r_t'].rhat.size(0)
+
+        g_pl2a = cache['g_pl2a'].window(u0 * A, (u0 + T) * A, n_src=P)
+        g_a2a = cache['g_a2a'].window(u0 * A, (u0 + T) * A, n_src=T * A, col_shift=u0 * A)
+        x_a = self._layers(x_a, map_enc['x_pl'][:, 0], g_t, cache['r_t'], g_pl2a, cache['r_pl2a'], g_a2a, cache['r_a2a'])
+        out = {'x_a': x_a}
+        if return_edge_index:   # the reference-order COO lists of this frame (costs host round trips)
+            lo, hi = int(cache['off_pl2a'][u0 * P]), int(cache['off_pl2a'][(u0 + T) * P])
+            shift = cache['g_pl2a'].edge_index.new_tensor([[u0 * P], [u0 * A]])
+            out['edge_index_pl2a'] = cache['g_pl2a'].edge_index[:, lo:hi] - shift
+            lo, hi = int(cache['off_a2a'][u0 * A]), int(cache['off_a2a'][(u0 + T) * A])
+            out['edge_index_a2a'] = cache['g_a2a'].edge_index[:, lo:hi] - u0 * A
+            out['edge_index_t'] = ei_t
+        return out
+
+    def forward(self, data, map_enc: Mapping[str, torch.Tensor], time_shift: int, cache=None,
+                return_edge_index: Optional[bool] = None) -> Dict[str, torch.Tensor]:
+        """``cache``: result of :meth:`precompute` for a range of time shifts containing ``time_shift`` (same output,
+        the shift-invariant work is not repeated).  The ``edge_index_*`` entries are this implementation's extras
+        (the reference returns only ``x_a``); with a cache they are produced only on request."""
+        if cache is not None:
+            return self._forward_cached(data, map_enc, time_shift, cache, bool(return_edge_index))
+        T, ts = self.num_historical_steps, int(time_shift)
+        agent = data['agent']
+        A = int(agent['num_nodes'])
+        mask = agent['valid_mask'][:, ts:T + ts].contiguous()
+        pos_a = agent['position'][:, ts:T + ts, :2].contiguous()
+        head_a = agent['heading'][:, ts:T + ts].contiguous()
+        vel = agent['velocity'][:, ts:T + ts, :2].contiguous()
+        prev = torch.cat([pos_a[:, :1], pos_a[:, :-1]], dim=1)           # zero motion vector at the first step (:99)
+        # one type embedding per agent, shared by its T steps (reference: repeat_interleave(T), :109)
+        x_a = self.x_a_emb(continuous_inputs=self._agent_features(pos_a, prev, head_a, vel).view(-1, 4),
+                           categorical_embs=[self.type_a_emb(agent['type'].long())], categorical_repeat=T)
+
+        pos_t, head_t = pos_a.reshape(-1, 2), head_a.reshape(-1)
+        ei_t = self._temporal_edges(mask)
+        g_t = CSRGraph.from_edge_index(ei_t, A * T, A * T, validate=False)
+        r_t = NormalizedEdgeFeatures(self.r_t_emb(
+            continuous_inputs=rel_geometry(pos_t, pos_t, head_t, head_t, ei_t, extra=ei_t[0] - ei_t[1]),
+            categorical_embs=None, normalized_output=True))
+        rel = self._spatial_relations(data, pos_a, head_a, mask, T)
+        x_a = self._layers(x_a.view(-1, T, self.hidden_dim), map_enc['x_pl'][:, 0], g_t, r_t, rel['g_pl2a'],
+                           rel['r_pl2a'], rel['g_a2a'], rel['r_a2a'])
+        return {'x_a': x_a, 'edge_index_t': ei_t, 'edge_index_pl2a': rel['g_pl2a'].edge_index,
+                'edge_index_a2a': rel['g_a2a'].edge_index}

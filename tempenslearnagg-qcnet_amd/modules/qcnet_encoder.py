@@ -33,10 +33,12 @@ class QCNetEncoder(nn.Module):
         self.agent_encoder = QCNetAgentEncoder(time_span=time_span, pl2a_radius=pl2a_radius, a2a_radius=a2a_radius,
                                                num_layers=num_agent_layers, **shared)
 
-    def forward(self, data, time_shift: int, map_enc: Optional[Dict[str, torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    def forward(self, data, time_shift: int, map_enc: Optional[Dict[str, torch.Tensor]] = None,
+                agent_cache=None) -> Dict[str, torch.Tensor]:
         """``map_enc``: a map encoding computed earlier for the same scene.  The map encoder takes no
-        ``time_shift`` (modules/qcnet_map_encoder.py:95), so the sliding loop may encode the map once."""
+        ``time_shift`` (modules/qcnet_map_encoder.py:95), so the sliding loop may encode the map once.
+        ``agent_cache``: ``agent_encoder.precompute(...)`` of the same scene (shift-invariant agent-side work)."""
         if map_enc is None:
             map_enc = self.map_encoder(data)
-        agent_enc = self.agent_encoder(data, map_enc, time_shift)
+        agent_enc = self.agent_encoder(data, map_enc, time_shift, cache=agent_cache)
         return {**map_enc, **agent_enc}

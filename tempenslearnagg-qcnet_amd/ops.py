@@ -212,15 +212,18 @@ LAYOUT_PLAIN, LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR = 0, 1, 2
 
 def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Tensor, rowptr: torch.Tensor,
                col: torch.Tensor, eid: Optional[torch.Tensor], wk: torch.Tensor, wv: torch.Tensor, bv: torch.Tensor,
-               rep: int = 1, layout: int = LAYOUT_PLAIN) -> torch.Tensor:
-    """qcn_attn_fused_f32: attention propagate with the positional projections folded into the kernel."""
+               rep: int = 1, layout: int = LAYOUT_PLAIN, col_shift: int = 0) -> torch.Tensor:
+    """qcn_attn_fused_f32: attention propagate with the positional projections folded into the kernel.
+    ``rowptr`` may be a window (view) of a larger graph's row pointer: its entries index ``col`` / ``eid`` / ``rhat``
+    absolutely; ``col_shift`` re-bases the source ids of such a window."""
     dev = q.device
     n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
     n_rows = rowptr.numel() - 1
     _require(q, 'q', torch.float32, dev, (n_dst, C))
     _require(k, 'k', torch.float32, dev, (n_src, C))
     _require(v, 'v', torch.float32, dev, (n_src, C))
-    _require(rhat, 'rhat', torch.float32, dev, (num_edges, C))
+    # with eid the feature table may be larger than the edge list (windows of an absolute-time relation)
+    _require(rhat, 'rhat', torch.float32, dev, (None if eid is not None else num_edges, C))
     _require(rowptr, 'rowptr', torch.int32, dev, (n_rows + 1,))
     _require(col, 'col', torch.int32, dev, (num_edges,))
     if eid is not None:
@@ -233,7 +236,7 @@ def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Te
     out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_attn_fused_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat), _ptr(rowptr), _ptr(col), _ptr(eid),
                                              _ptr(wk), _ptr(wv), _ptr(bv), n_dst, n_src, n_rows, num_edges, int(rep),
-                                             int(layout), _ptr(out), _stream(dev)), 'qcn_attn_fused_f32')
+                                             int(layout), int(col_shift), _ptr(out), _stream(dev)), 'qcn_attn_fused_f32')
     return out
 
 

@@ -36,9 +36,13 @@ class TempEnsLearnAgg(nn.Module):
         self.temporal_aggregate_layer.load_state_dict(self.base_model.decoder.state_dict())
         # The map encoder does not depend on time_shift; the reference recomputes it for every frame.
         self.share_map_encoding = share_map_encoding
+        # Consecutive frames share 49 of their 50 history steps: agent features, spatial neighbourhoods and their
+        # positional embeddings depend on absolute time only (modules/qcnet_agent_encoder.py precompute).
+        self.share_frame_work = share_map_encoding
 
-    def forward(self, data, time_shift: int, map_enc=None) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
-        scene_enc = self.base_model.encoder(data, time_shift, map_enc=map_enc)
+    def forward(self, data, time_shift: int, map_enc=None, agent_cache=None
+                ) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
+        scene_enc = self.base_model.encoder(data, time_shift, map_enc=map_enc, agent_cache=agent_cache)
         pred = self.base_model.decoder(data, scene_enc, time_shift)
         return pred, scene_enc
 
@@ -46,10 +50,13 @@ class TempEnsLearnAgg(nn.Module):
     def predict(self, data) -> Dict[str, torch.Tensor]:
         """Ten sliding QCNet frames + learned aggregation (reference :196-221, :261)."""
         map_enc = self.base_model.encoder.map_encoder(data) if self.share_map_encoding else None
+        agent_cache = None
+        if self.share_frame_work:
+            agent_cache = self.base_model.encoder.agent_encoder.precompute(data, 1, self.num_frames)
         temporal_m = []
         scene_enc = None
         for time_shift in range(1, self.num_frames + 1):
-            pred, scene_enc = self(data, time_shift, map_enc=map_enc)
+            pred, scene_enc = self(data, time_shift, map_enc=map_enc, agent_cache=agent_cache)
             temporal_m.append(pred['m'])
         temporal_m = torch.stack(temporal_m, dim=1)
         pred = self.temporal_aggregate_layer(temporal_m, data, scene_enc, self.num_frames)

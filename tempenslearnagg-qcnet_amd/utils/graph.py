@@ -28,9 +28,10 @@ class CSRGraph:
     ``i`` lives in the destination tensor: ``LAYOUT_MODE_MAJOR`` → ``m * n_rows + i``, ``LAYOUT_AGENT_MAJOR`` →
     ``i * rep + m``.  ``edge_index`` still holds the reference's replicated COO list (E = E_base * rep)."""
 
-    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid', 'rep', 'layout')
+    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid', 'rep', 'layout', 'col_shift', 'num_feature_rows')
 
-    def __init__(self, edge_index, n_src, n_dst, rowptr, col, eid, rep: int = 1, layout: int = ops.LAYOUT_PLAIN):
+    def __init__(self, edge_index, n_src, n_dst, rowptr, col, eid, rep: int = 1, layout: int = ops.LAYOUT_PLAIN,
+                 col_shift: int = 0, num_feature_rows: Optional[int] = None):
         self.edge_index = edge_index
         self.n_src = int(n_src)
         self.n_dst = int(n_dst)
@@ -39,6 +40,10 @@ class CSRGraph:
         self.eid = eid
         self.rep = int(rep)
         self.layout = int(layout)
+        # windows of a larger (absolute-time) relation: rowptr is a view with absolute offsets into col / eid, source
+        # ids are re-based by col_shift and the positional-feature table has num_feature_rows rows
+        self.col_shift = int(col_shift)
+        self.num_feature_rows = int(num_feature_rows) if num_feature_rows is not None else int(col.numel())
 
     @property
     def num_base_edges(self) -> int:
@@ -73,7 +78,14 @@ class CSRGraph:
         modules/qcnet_map_encoder.py:170, and K times, modules/qcnet_decoder.py:150-151) are gathered from one
         copy: source index modulo ``period``.  ``edge_index`` keeps the reference numbering."""
         return CSRGraph(self.edge_index, period, self.n_dst, self.rowptr, torch.remainder(self.col, period), self.eid,
-                        self.rep, self.layout)
+                        self.rep, self.layout, self.col_shift, self.num_feature_rows)
+
+    def window(self, row_begin: int, row_end: int, n_src: int, col_shift: int = 0) -> 'CSRGraph':
+        """Rows [row_begin, row_end) as a graph of their own without copying anything: the row pointer is a view
+        (offsets stay absolute), sources are re-based by ``col_shift``.  ``edge_index`` is not carried over."""
+        assert self.rep == 1
+        return CSRGraph(None, n_src, row_end - row_begin, self.rowptr[row_begin:row_end + 1], self.col, self.eid,
+                        col_shift=col_shift, num_feature_rows=self.num_feature_rows)
 
     def replicate(self, rep: int, layout: int, edge_index: Optional[torch.Tensor] = None) -> 'CSRGraph':
         """The same edge list for ``rep`` mode copies of every destination row (see class docstring).

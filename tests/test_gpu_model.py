@@ -112,13 +112,34 @@ def test_temp_ens_learn_agg_vs_oracle():
         want = oracle.temp_ens_learn_agg_forward(sd, batch, cfg['hparams'])
         model = model.to(DEV)
         got = model.predict(batch.to(DEV))
-        model.share_map_encoding = False                       # the reference's own loop (map encoder per frame)
+        model.share_map_encoding = model.share_frame_work = False   # the reference's own loop: everything per frame
         got_ref_loop = model.predict(batch.to(DEV))
     for k in ('traj_refine', 'pi_softmax', 'final_m', 'loc_refine_pos', 'scale_refine_pos', 'pi'):
         assert rel_err(got[k], want[k]) < TOL, k
         assert torch.equal(got[k], got_ref_loop[k]), k
     assert got['traj_refine'].shape == (batch['agent']['num_nodes'], 6, 50, 4)
     assert torch.allclose(got['pi_softmax'].sum(-1), torch.ones(batch['agent']['num_nodes'], device=DEV), atol=1e-5)
+
+
+@pytest.mark.parametrize('cfg_name,ids', [('tiny', [0, 1, 2]), ('cfg1', [4])])
+def test_frame_reuse_cache_equals_per_frame_encoding(cfg_name, ids):
+    """The absolute-time cache (agent_encoder.precompute) reproduces the per-frame encoder bit for bit, including
+    the reference-order edge lists, for every time shift of the sliding loop."""
+    cfg = config_scene(cfg_name)
+    model = _model(cfg).to(DEV)
+    batch = make_batch(ids, **cfg['scene']).to(DEV)
+    enc = model.base_model.encoder
+    with torch.no_grad():
+        map_enc = enc.map_encoder(batch)
+        cache = enc.agent_encoder.precompute(batch, 1, 10)
+        for ts in (1, 4, 10):
+            want = enc.agent_encoder(batch, map_enc, ts)
+            got = enc.agent_encoder(batch, map_enc, ts, cache=cache, return_edge_index=True)
+            for k in ('edge_index_t', 'edge_index_pl2a', 'edge_index_a2a'):
+                assert torch.equal(got[k], want[k]), (k, ts)
+            assert torch.equal(got['x_a'], want['x_a']), ts
+        with pytest.raises(ValueError):
+            enc.agent_encoder(batch, map_enc, 11, cache=cache)
 
 
 def test_scenarios_are_independent_full_size():
