@@ -154,6 +154,13 @@ size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
                       const float *pack, int64_t n_rows, float *out, void *stream);
 
+/* K10 — recurrent half of the decoder's nn.GRU(128,128) trajectory embedder (modules/qcnet_decoder.py:86-88,257),
+ * final hidden state only.  gi_r / gi_z / gi_n [n_seq * n_steps, 128]: the input half W_i* x_t + b_i* for row
+ * seq * n_steps + t (one qcn_ln_linear_f32 call without LayerNorm); whh_t [128, 384] = weight_hh_l0^T (gate order r, z, n);
+ * b_hh [384]; h0 [128] (broadcast to every sequence); h_out [n_seq, 128]. */
+int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh_t,
+                const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, void *stream);
+
 /* K6 — y = (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine; the layer-independent half
  * of attn_prenorm_r, layers/attention_layer.py:63,82). */
 int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);

@@ -87,6 +87,20 @@ class QCNetDecoder(nn.Module):
         self.to_pi = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=1)
         self.apply(weight_init)
 
+    def _gru_packs(self):
+        """traj_emb parameters in the kernels' layouts (k-major transposes), cached per parameter version."""
+        gru = self.traj_emb
+        prm = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0, self.traj_emb_h0)
+        key = tuple((p.data_ptr(), p._version) for p in prm)
+        if key != getattr(self, '_gru_key', None):
+            C = self.hidden_dim
+            with torch.no_grad():
+                wih_t = gru.weight_ih_l0.view(3, C, C).transpose(1, 2).contiguous()
+                self._gru_pack = (wih_t, gru.bias_ih_l0.view(3, C).contiguous(), gru.weight_hh_l0.t().contiguous(),
+                                  gru.bias_hh_l0.contiguous(), self.traj_emb_h0.reshape(-1).contiguous())
+            self._gru_key = key
+        return self._gru_pack
+
     # hook: TemporalAggregate sums the stored mode queries of the earlier frames into the new ones here
     def _fuse_modes(self, m: torch.Tensor, temporal_m: Optional[torch.Tensor]) -> torch.Tensor:
         return m
@@ -175,9 +189,10 @@ class QCNetDecoder(nn.Module):
         loc_propose_head = loc_propose_pos.new_zeros((A, K, Tf, 1))
         conc_propose_head = scale_propose_pos.new_zeros((A, K, Tf, 1))
 
+        # trajectory re-encoding: Fourier embedding of the proposed way-points, GRU over the Tf steps, last hidden state
+        # (reference :255-257); row n * Tf + t of the embedding is step t of mode query n
         m = self.y_emb(loc_propose_pos.detach().reshape(-1, OD))
-        m = m.reshape(-1, Tf, C).transpose(0, 1)
-        m = self.traj_emb(m, self.traj_emb_h0.unsqueeze(1).repeat(1, m.size(1), 1))[1].squeeze(0)
+        m = ops.gru_last_hidden(m, Tf, *self._gru_packs())
         m = self._fuse_modes(m, temporal_m)
         m = self._cross_stack('refine', m, *graphs)
 

@@ -207,6 +207,26 @@ def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_r
     return out
 
 
+def gru_last_hidden(x_seq: torch.Tensor, n_steps: int, wih_t: torch.Tensor, b_ih: torch.Tensor, whh_t: torch.Tensor,
+                    b_hh: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
+    """Final hidden state of a 1-layer GRU(128, 128) over ``n_steps`` steps.  ``x_seq`` [n_seq * n_steps, 128] with
+    row = seq * n_steps + t; ``wih_t`` [3, 128, 128] k-major per gate (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` [128, 384];
+    ``b_hh`` [384]; ``h0`` [128].  Input half: one qcn_ln_linear_f32 launch; recurrence: one qcn_gru_f32 launch."""
+    dev = x_seq.device
+    _require(x_seq, 'x_seq', torch.float32, dev, (None, C))
+    if x_seq.size(0) % n_steps:
+        raise ValueError('x_seq rows (%d) not a multiple of n_steps (%d)' % (x_seq.size(0), n_steps))
+    n_seq = x_seq.size(0) // n_steps
+    _require(whh_t, 'whh_t', torch.float32, dev, (C, 3 * C))
+    _require(b_hh, 'b_hh', torch.float32, dev, (3 * C,))
+    _require(h0, 'h0', torch.float32, dev, (C,))
+    (gi_r, gi_z, gi_n), _ = ln_linear(x_seq, None, None, wih_t, b_ih)
+    h = torch.empty(n_seq, C, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_gru_f32(_ptr(gi_r), _ptr(gi_z), _ptr(gi_n), _ptr(whh_t), _ptr(b_hh), _ptr(h0), n_seq,
+                                      int(n_steps), _ptr(h), _stream(dev)), 'qcn_gru_f32')
+    return h
+
+
 LAYOUT_PLAIN, LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR = 0, 1, 2
 
 

@@ -193,3 +193,23 @@ def test_attn_fused_mode_replication_equals_explicit_graph(layout):
     g = CSRGraph.from_edge_index(base.to(DEV), n_src, n_rows).replicate(K, layout)
     got = _fused(q, k, v, r, g, *pw, rep=K, layout=layout)
     assert rel_err(got, want) < 2e-5
+
+
+def test_gru_kernel_matches_torch_gru():
+    """qcn_gru_f32 + input GEMM against torch.nn.GRU (CPU fp32), ragged sequence count (tail block)."""
+    torch.manual_seed(11)
+    gru = torch.nn.GRU(128, 128).eval()
+    with torch.no_grad():
+        for p in gru.parameters():
+            p.copy_(torch.randn_like(p) * 0.12)
+    n_seq, n_steps = 77, 60
+    seq = torch.randn(n_steps, n_seq, 128)
+    h0 = torch.randn(128) * 0.3
+    with torch.no_grad():
+        want = gru(seq, h0.view(1, 1, 128).repeat(1, n_seq, 1))[1].squeeze(0)
+    x = seq.transpose(0, 1).reshape(-1, 128).contiguous().to(DEV)          # row = seq * n_steps + t
+    wih_t = gru.weight_ih_l0.detach().view(3, 128, 128).transpose(1, 2).contiguous().to(DEV)
+    got = ops.gru_last_hidden(x, n_steps, wih_t, gru.bias_ih_l0.detach().view(3, 128).contiguous().to(DEV),
+                              gru.weight_hh_l0.detach().t().contiguous().to(DEV), gru.bias_hh_l0.detach().to(DEV),
+                              h0.to(DEV))
+    assert rel_err(got, want) < 1e-5
