@@ -112,11 +112,16 @@ int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, const float
  * rowptr [n_rows+1], col / eid [E_base] as in qcn_csr_build (eid NULL: rhat rows are in CSR order).
  * rowptr entries are offsets into col / eid and need not start at 0: a window of consecutive rows of a larger graph is
  * passed as a pointer into that graph's rowptr (the sliding frames of predictors/temp_ens_learn_agg.py:197 are such
- * windows of one absolute-time graph); col_shift is subtracted from every col entry to re-base source ids. */
+ * windows of one absolute-time graph); col_shift is subtracted from every col entry to re-base source ids.
+ * group_host (HOST pointer to 4 int64, or NULL): all frames in one launch.  {group_rows, group_row_shift,
+ * group_col_shift, group_src_stride}: destination idx belongs to frame g = idx / group_rows and uses CSR row
+ * idx % group_rows + g * group_row_shift; its sources are rows col - col_shift - g * group_col_shift + g * group_src_stride
+ * of k / v (n_rows = rows of the absolute graph, layout 0, rep 1, n_dst = frames * group_rows). */
 int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const float *rhat,
                        const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *wk,
                        const float *wv, const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows,
-                       int64_t num_edges, int rep, int layout, int64_t col_shift, float *out, void *stream);
+                       int64_t num_edges, int rep, int layout, int64_t col_shift, const int64_t *group_host,
+                       float *out, void *stream);
 
 /* A4 — the whole FourierEmbedding.forward (layers/fourier_embedding.py:49-67) in one launch:
  *   x [n_rows, input_dim] (input_dim 0..4; NULL for 0), extra [ceil(n_rows / extra_div), 128] or NULL = the summed

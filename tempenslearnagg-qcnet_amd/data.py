@@ -139,3 +139,43 @@ class Batch(HeteroData):
             if key not in out._stores:  # global attributes (scenario_id, city, ...)
                 out[key] = [d[key] for d in data_list]
         return out
+
+
+def frame_batch(data: HeteroData, first_shift: int, n_frames: int, num_steps: int) -> Batch:
+    """The sliding frames of one batch as ONE larger batch: scenario (f, b) is scenario b seen ``f`` steps later.
+
+    Agent time series are shifted so that ``module(frame_batch(data, s0, F, n), ..., time_shift=s0)`` computes for rows
+    [f * A, (f + 1) * A) what ``module(data, ..., time_shift=s0 + f)`` computes (``num_steps`` = steps kept after the
+    shift; the decoder reads up to ``num_historical_steps + time_shift``).  ``predict_mask`` is only ever reduced with
+    ``.any(-1)`` (modules/qcnet_decoder.py:156) and is replicated unshifted; map stores are replicated per frame."""
+    F = int(n_frames)
+    num_graphs = getattr(data, 'num_graphs', 1)
+    out = Batch(num_graphs=num_graphs * F)
+    agent = data['agent']
+    A = int(agent['num_nodes'])
+    store = {'num_nodes': A * F}
+    for name, value in agent.items():
+        if not torch.is_tensor(value) or name in ('batch', 'ptr'):
+            continue
+        if name in ('position', 'heading', 'velocity', 'valid_mask'):
+            store[name] = torch.cat([value[:, f:f + num_steps] for f in range(F)], dim=0)
+        else:
+            store[name] = value.repeat(F, *([1] * (value.dim() - 1)))
+    out['agent'] = store
+    for ntype in data.node_types:
+        if ntype != 'agent':
+            n = int(data[ntype]['num_nodes'])
+            out[ntype] = {'num_nodes': n * F}
+            for name, value in data[ntype].items():
+                if torch.is_tensor(value) and name not in ('batch', 'ptr'):
+                    out[ntype][name] = value.repeat(F, *([1] * (value.dim() - 1)))
+    for ntype in data.node_types:
+        n = int(data[ntype]['num_nodes'])
+        dev = data[ntype]['position'].device
+        ptr = data[ntype].get('ptr')
+        ptr = ptr.to(dev) if ptr is not None else torch.tensor([0, n], device=dev)
+        offs = (torch.arange(F, device=dev).unsqueeze(1) * n + ptr[:-1].unsqueeze(0)).reshape(-1)
+        out[ntype]['ptr'] = torch.cat([offs, ptr.new_tensor([n * F])])
+        counts = out[ntype]['ptr'][1:] - out[ntype]['ptr'][:-1]
+        out[ntype]['batch'] = torch.repeat_interleave(torch.arange(num_graphs * F, device=dev), counts)
+    return out

@@ -159,9 +159,9 @@ class AttentionLayer(nn.Module):
         if r is not None:
             wk, wv, bv = packs['pos']
             agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep, graph.layout,
-                                 graph.col_shift)
+                                 graph.col_shift, graph.group)
         else:
-            if graph.rep != 1 or graph.col_shift != 0:
+            if graph.rep != 1 or graph.col_shift != 0 or graph.group is not None:
                 raise ValueError('mode-replicated / windowed graphs need a positional embedding')
             agg = ops.attn_fwd(q, k, v, None, None, graph.rowptr, graph.col, graph.eid)
         # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)

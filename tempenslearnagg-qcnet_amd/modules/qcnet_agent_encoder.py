@@ -197,6 +197,42 @@ class QCNetAgentEncoder(nn.Module):
             out['edge_index_t'] = ei_t
         return out
 
+    @torch.no_grad()
+    def forward_frames(self, data, map_enc: Mapping[str, torch.Tensor], cache) -> torch.Tensor:
+        """All frames of the precomputed range in ONE pass: returns ``x_a`` [F * A, T, C] with frame f (time shift
+        first_shift + f) in rows [f * A, (f + 1) * A) — row for row what ``forward(data, map_enc, first_shift + f)``
+        gives.  Every layer is launched once over the F-fold destination set: the spatial relations are frame groups of
+        the absolute-time CSR (``CSRGraph.frames``), the temporal relation is one edge list over all frames."""
+        T, C = self.num_historical_steps, self.hidden_dim
+        A, P = int(data['agent']['num_nodes']), int(data['map_polygon']['num_nodes'])
+        F = cache['n_frames']
+        dev = cache['x_main'].device
+        # frame f, step t -> absolute step f + t (its first step takes the zero-motion variant)
+        steps = torch.arange(F, device=dev).unsqueeze(1) + torch.arange(1, T, device=dev).unsqueeze(0)     # [F, T-1]
+        x_a = torch.cat([cache['x_first'].transpose(0, 1).unsqueeze(2),
+                         cache['x_main'][:, steps].permute(1, 0, 2, 3)], dim=2)                             # [F, A, T, C]
+
+        f_ids = torch.arange(F, device=dev).unsqueeze(1)
+        keep = (cache['t_src'].unsqueeze(0) >= f_ids) & (cache['t_dst'].unsqueeze(0) < f_ids + T)          # [F, E_abs]
+        f_sel, e_sel = keep.nonzero(as_tuple=True)
+        base = (f_sel * A + cache['t_agent'][e_sel]) * T - f_sel
+        ei_t = torch.stack([base + cache['t_src'][e_sel], base + cache['t_dst'][e_sel]], dim=0)
+        g_t = CSRGraph.from_edge_index(ei_t, F * A * T, F * A * T, validate=False)
+        g_t.eid = e_sel.to(torch.int32)[g_t.eid.long()]
+        g_t.num_feature_rows = cache['r_t'].rhat.size(0)
+
+        g_pl2a = cache['g_pl2a'].frames(F, T * A, A, n_src=P)
+        g_a2a = cache['g_a2a'].frames(F, T * A, A, n_src=F * T * A, col_shift=A, src_stride=T * A)
+        x_pl = map_enc['x_pl'][:, 0]
+        for i in range(self.num_layers):
+            x_a = x_a.reshape(-1, C)                                                     # (f, a, t)
+            x_a = self.t_attn_layers[i](x_a, cache['r_t'], g_t)
+            x_a = x_a.view(F, A, T, C).transpose(1, 2).reshape(-1, C)                    # (f, t, a)
+            x_a = self.pl2a_attn_layers[i]((x_pl, x_a), cache['r_pl2a'], g_pl2a)
+            x_a = self.a2a_attn_layers[i](x_a, cache['r_a2a'], g_a2a)
+            x_a = x_a.view(F, T, A, C).transpose(1, 2)                                   # (f, a, t)
+        return x_a.reshape(F * A, T, C)
+
     def forward(self, data, map_enc: Mapping[str, torch.Tensor], time_shift: int, cache=None,
                 return_edge_index: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """``cache``: result of :meth:`precompute` for a range of time shifts containing ``time_shift`` (same output,

@@ -39,6 +39,9 @@ class TempEnsLearnAgg(nn.Module):
         # Consecutive frames share 49 of their 50 history steps: agent features, spatial neighbourhoods and their
         # positional embeddings depend on absolute time only (modules/qcnet_agent_encoder.py precompute).
         self.share_frame_work = share_map_encoding
+        # The ten frames are independent given the shared work, so they run as ONE ten-fold batch: every layer is
+        # one launch over all frames instead of ten small ones.
+        self.batch_frames = share_map_encoding
 
     def forward(self, data, time_shift: int, map_enc=None, agent_cache=None
                 ) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
@@ -46,9 +49,35 @@ class TempEnsLearnAgg(nn.Module):
         pred = self.base_model.decoder(data, scene_enc, time_shift)
         return pred, scene_enc
 
+    def _finish(self, pred: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        traj_refine = torch.cat([pred['loc_refine_pos'][..., :self.output_dim],
+                                 pred['scale_refine_pos'][..., :self.output_dim]], dim=-1)
+        pred['traj_refine'] = traj_refine[..., :50, :]
+        pred['pi_softmax'] = F.softmax(pred['pi'], dim=-1)
+        return pred
+
+    @torch.no_grad()
+    def _predict_frames_batched(self, data) -> Dict[str, torch.Tensor]:
+        from ..data import frame_batch
+        T, n_f = self.num_historical_steps, self.num_frames
+        enc, dec = self.base_model.encoder, self.base_model.decoder
+        A = int(data['agent']['num_nodes'])
+        map_enc = enc.map_encoder(data)
+        cache = enc.agent_encoder.precompute(data, 1, n_f)
+        x_a = enc.agent_encoder.forward_frames(data, map_enc, cache)                       # [F * A, T, C]
+        frames = frame_batch(data, 1, n_f, T + 2)
+        x_pl = map_enc['x_pl'][:, 0]
+        scene = {'x_a': x_a, 'x_pl': x_pl.repeat(n_f, 1).unsqueeze(1).expand(-1, T, -1)}
+        pred = dec(frames, scene, 1)
+        temporal_m = pred['m'].view(n_f, A, self.num_modes, self.hidden_dim).transpose(0, 1)
+        scene_last = {'x_a': x_a[(n_f - 1) * A:], 'x_pl': map_enc['x_pl']}
+        return self._finish(self.temporal_aggregate_layer(temporal_m, data, scene_last, n_f))
+
     @torch.no_grad()
     def predict(self, data) -> Dict[str, torch.Tensor]:
         """Ten sliding QCNet frames + learned aggregation (reference :196-221, :261)."""
+        if self.batch_frames and self.share_map_encoding and self.share_frame_work:
+            return self._predict_frames_batched(data)
         map_enc = self.base_model.encoder.map_encoder(data) if self.share_map_encoding else None
         agent_cache = None
         if self.share_frame_work:
@@ -59,9 +88,4 @@ class TempEnsLearnAgg(nn.Module):
             pred, scene_enc = self(data, time_shift, map_enc=map_enc, agent_cache=agent_cache)
             temporal_m.append(pred['m'])
         temporal_m = torch.stack(temporal_m, dim=1)
-        pred = self.temporal_aggregate_layer(temporal_m, data, scene_enc, self.num_frames)
-        traj_refine = torch.cat([pred['loc_refine_pos'][..., :self.output_dim],
-                                 pred['scale_refine_pos'][..., :self.output_dim]], dim=-1)
-        pred['traj_refine'] = traj_refine[..., :50, :]
-        pred['pi_softmax'] = F.softmax(pred['pi'], dim=-1)
-        return pred
+        return self._finish(self.temporal_aggregate_layer(temporal_m, data, scene_enc, self.num_frames))

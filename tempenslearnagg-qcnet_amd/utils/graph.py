@@ -28,7 +28,7 @@ class CSRGraph:
     ``i`` lives in the destination tensor: ``LAYOUT_MODE_MAJOR`` → ``m * n_rows + i``, ``LAYOUT_AGENT_MAJOR`` →
     ``i * rep + m``.  ``edge_index`` still holds the reference's replicated COO list (E = E_base * rep)."""
 
-    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid', 'rep', 'layout', 'col_shift', 'num_feature_rows')
+    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid', 'rep', 'layout', 'col_shift', 'num_feature_rows', 'group')
 
     def __init__(self, edge_index, n_src, n_dst, rowptr, col, eid, rep: int = 1, layout: int = ops.LAYOUT_PLAIN,
                  col_shift: int = 0, num_feature_rows: Optional[int] = None):
@@ -44,6 +44,7 @@ class CSRGraph:
         # ids are re-based by col_shift and the positional-feature table has num_feature_rows rows
         self.col_shift = int(col_shift)
         self.num_feature_rows = int(num_feature_rows) if num_feature_rows is not None else int(col.numel())
+        self.group = None   # (group_rows, group_row_shift, group_col_shift, group_src_stride): see frames()
 
     @property
     def num_base_edges(self) -> int:
@@ -86,6 +87,17 @@ class CSRGraph:
         assert self.rep == 1
         return CSRGraph(None, n_src, row_end - row_begin, self.rowptr[row_begin:row_end + 1], self.col, self.eid,
                         col_shift=col_shift, num_feature_rows=self.num_feature_rows)
+
+    def frames(self, n_frames: int, rows_per_frame: int, row_shift: int, n_src: int, col_shift: int = 0,
+               src_stride: int = 0) -> 'CSRGraph':
+        """All sliding frames of an absolute-time relation as ONE graph without copying: frame f owns destinations
+        [f * rows_per_frame, (f + 1) * rows_per_frame), which are CSR rows [f * row_shift, f * row_shift + rows_per_frame);
+        its source ids are col - f * col_shift + f * src_stride."""
+        assert self.rep == 1 and self.group is None
+        g = CSRGraph(None, n_src, n_frames * rows_per_frame, self.rowptr, self.col, self.eid,
+                     num_feature_rows=self.num_feature_rows)
+        g.group = (int(rows_per_frame), int(row_shift), int(col_shift), int(src_stride))
+        return g
 
     def replicate(self, rep: int, layout: int, edge_index: Optional[torch.Tensor] = None) -> 'CSRGraph':
         """The same edge list for ``rep`` mode copies of every destination row (see class docstring).

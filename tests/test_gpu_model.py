@@ -112,11 +112,16 @@ def test_temp_ens_learn_agg_vs_oracle():
         want = oracle.temp_ens_learn_agg_forward(sd, batch, cfg['hparams'])
         model = model.to(DEV)
         got = model.predict(batch.to(DEV))
+        model.batch_frames = False                                  # frame loop with shared map / absolute-time work
+        got_loop = model.predict(batch.to(DEV))
         model.share_map_encoding = model.share_frame_work = False   # the reference's own loop: everything per frame
         got_ref_loop = model.predict(batch.to(DEV))
     for k in ('traj_refine', 'pi_softmax', 'final_m', 'loc_refine_pos', 'scale_refine_pos', 'pi'):
         assert rel_err(got[k], want[k]) < TOL, k
-        assert torch.equal(got[k], got_ref_loop[k]), k
+        # sharing the map / absolute-time work does not change a bit; running the ten frames as one batch changes the
+        # library GEMM tiling of the MLP heads (M is ten times larger), hence rounding only
+        assert torch.equal(got_loop[k], got_ref_loop[k]), k
+        assert rel_err(got[k], got_loop[k]) < 1e-5, k
     assert got['traj_refine'].shape == (batch['agent']['num_nodes'], 6, 50, 4)
     assert torch.allclose(got['pi_softmax'].sum(-1), torch.ones(batch['agent']['num_nodes'], device=DEV), atol=1e-5)
 
