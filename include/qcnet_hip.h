@@ -123,16 +123,25 @@ int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const flo
                        int64_t num_edges, int rep, int layout, int64_t col_shift, const int64_t *group_host,
                        float *out, void *stream);
 
+/* Chain-packed 128x128 matrix — the weight layout of the three MFMA chain kernels below (csrc/chain_tile.hip.h).
+ * For W = nn.Linear(128,128).weight ([out][in]) the 16384 floats are
+ *   P[s][lane][t] = W[32 t + (lane & 31)][kin(s, lane >> 5)],   s = 0..63, lane = 0..63, t = 0..3,
+ * where kin(s, h) = 32 (s >> 4) + (s & 3) + 8 ((s & 15) >> 2) + 4 h is the input feature that k-step s of the
+ * v_mfma_f32_32x32x2_f32 chain takes from lane half h (the register layout of a row vector).  The first layer of a
+ * FourierEmbedding MLP uses kin(s, h) = 32 h + s for s < 32 (cosines) and 64 + 32 h + (s - 32) otherwise (sines).
+ * Host packer: ops.pack_chain_matrix. */
+
 /* A4 — the whole FourierEmbedding.forward (layers/fourier_embedding.py:49-67) in one launch:
  *   x [n_rows, input_dim] (input_dim 0..4; NULL for 0), extra [ceil(n_rows / extra_div), 128] or NULL = the summed
  *   categorical embeddings, row n of the output uses extra row n / extra_div (modules/qcnet_agent_encoder.py:109
  *   repeats one type embedding per agent over T steps: extra_div = T); y [n_rows, 128].
  *   normalize_out != 0 additionally applies (y - mean) / sqrt(var + 1e-5) per row, the layer-independent half of the
  *   consuming AttentionLayers' attn_prenorm_r (layers/attention_layer.py:82).
- *   pack: qcn_fourier_pack_floats(input_dim) floats, per input dim i
- *     [freqs.weight[i] (64) | mlps.i.0.weight[:, :128]^T (k-major 128x128) | mlps.i.0.weight[:, 128] | mlps.i.0.bias |
- *      mlps.i.1.weight | mlps.i.1.bias | mlps.i.3.weight^T (k-major) | mlps.i.3.bias]
- *   followed by [to_out.0.weight | to_out.0.bias | to_out.2.weight^T (k-major) | to_out.2.bias].
+ *   pack: qcn_fourier_pack_floats(input_dim) floats: the 2 input_dim + 1 chain-packed matrices
+ *     [mlps.0.0.weight[:, :128] (cos | sin order above), mlps.0.3.weight, mlps.1.0.weight[:, :128], ..., to_out.2.weight]
+ *   then per input dim i
+ *     [freqs.weight[i] (64) | mlps.i.0.weight[:, 128] | mlps.i.0.bias | mlps.i.1.weight | mlps.i.1.bias | mlps.i.3.bias]
+ *   followed by [to_out.0.weight | to_out.0.bias | to_out.2.bias].
  *   hidden_dim = 128, num_freq_bands = 64 only. */
 size_t qcn_fourier_pack_floats(int input_dim);
 int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
@@ -140,8 +149,8 @@ int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int
 
 /* A2 node side (K5/K6 of SURVEY.md §2b fused) — xn = LayerNorm(x) (skipped when ln_weight == NULL);
  * y_j = W_j xn + b_j for j < n_out <= 4 (the to_q / to_k / to_v / to_s projections of one AttentionLayer call,
- * layers/attention_layer.py:74-79,115-117,108).  x, y_j, xn_out: [n_rows,128]; wt: n_out k-major matrices
- * (wt[j][k][n] = W_j[n][k]); bias: [n_out,128] or NULL; xn_out may be NULL. */
+ * layers/attention_layer.py:74-79,115-117,108).  x, y_j, xn_out: [n_rows,128]; wt: n_out chain-packed matrices
+ * (16384 floats each); bias: [n_out,128] or NULL; xn_out may be NULL. */
 int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
                       const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
                       float *y3, float *xn_out, void *stream);
@@ -150,11 +159,12 @@ int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, co
  * (layers/attention_layer.py:83-84,106-108,119,121-122):
  *   g = sigmoid(to_g [agg, xn_dst]); u = agg + g (s_proj - agg); x1 = x_res + LN_post(to_out u);
  *   out = x1 + LN_ffpost(ff_mlp.3 relu(ff_mlp.0 LN_ffpre(x1))).
- * pack (qcn_attn_post_pack_floats() floats): 11 k-major 128x128 matrices in consumption order
- *   [to_g.weight[:, :128]^T, to_g.weight[:, 128:]^T, to_out.weight^T, then for hb = 0..3:
- *    ff_mlp.0.weight[128hb:128hb+128, :]^T, ff_mlp.3.weight[:, 128hb:128hb+128]^T]
+ * pack (qcn_attn_post_pack_floats() floats): 11 chain-packed 128x128 matrices in consumption order
+ *   [to_g.weight[:, :128], to_g.weight[:, 128:], to_out.weight, then for hb = 0..3:
+ *    ff_mlp.0.weight[128hb:128hb+128, :], ff_mlp.3.weight[:, 128hb:128hb+128]]
  * followed by [to_g.bias, to_out.bias, attn_postnorm.{weight,bias}, ff_prenorm.{weight,bias}, ff_mlp.0.bias (512),
- *   ff_mlp.3.bias, ff_postnorm.{weight,bias}].  All tensors [n_rows,128] fp32. */
+ *   ff_mlp.3.bias, ff_postnorm.{weight,bias}].  All tensors [n_rows,128] fp32; out must not alias an input (it parks
+ * x1 between the two residuals). */
 size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
                       const float *pack, int64_t n_rows, float *out, void *stream);

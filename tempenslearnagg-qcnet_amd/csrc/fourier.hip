@@ -5,152 +5,118 @@
 // intermediates per input dim).  The contractions run on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32
 // fma chains, so the result stays within fp32 rounding of the reference — there is no reduced-precision step).
 //
-// Tiling: 128 rows per workgroup, 4 waves, each wave owns 32 complete rows (32 x 128 outputs = four 32x32 accumulator
-// tiles), so both LayerNorms are in-register reductions over the 32 lanes of a wave half — no cross-wave traffic.
-// A operand: the wave's private k-major LDS tile [128 k][32 rows] (+1 padding: conflict-free for the column-wise
-// stores of the LN output and the row-wise fragment reads).  B operand: the pre-transposed weights (k-major, packed
-// once on the host) streamed from L2 through a double-buffered 32-k LDS chunk shared by the 4 waves, one barrier per
-// chunk, the next chunk's global loads in flight under the current chunk's 64 MFMAs per wave.
-// MFMA-bound: 2*128*(129+128) flops per row and input dim + 2*128*128 for to_out.
-#include "mfma_tile.hip.h"
+// Feature-major chain (chain_tile.hip.h): a lane owns one row; the 128 Fourier features of an input dim are computed
+// straight into the MFMA operand registers (lane half h evaluates sincos for frequencies 32 h .. 32 h + 31: k-steps
+// 0..31 carry the cosines, 32..63 the sines, and W1 is packed on the host in that k order), the hidden vector after
+// LN + ReLU is the operand of the second layer, whose accumulator is the running sum over input dims; the 129th
+// input column (x itself) is a rank-1 term folded into the accumulator init.  LDS holds only the double-buffered
+// packed weights.  MFMA-bound: 2*128*(129+128) flops per row and input dim + 2*128*128 for to_out.
+#include "chain_tile.hip.h"
 
 namespace {
 
-using namespace qcn_tile;
+using namespace qcn_chain;
 
-constexpr int kF = 64;
-// packed parameter layout (floats); see ops.pack_fourier_weights
-constexpr int kOffFreq = 0;                       // [64]
-constexpr int kOffW1t = 64;                       // [128 k][128 n]
-constexpr int kOffW1Last = kOffW1t + kC * kC;     // [128]
-constexpr int kOffB1 = kOffW1Last + kC;
-constexpr int kOffG1 = kOffB1 + kC;
-constexpr int kOffBe1 = kOffG1 + kC;
-constexpr int kOffW2t = kOffBe1 + kC;             // [128 k][128 n]
-constexpr int kOffB2 = kOffW2t + kC * kC;
-constexpr int kDimStride = kOffB2 + kC;
-constexpr int kOutG = 0, kOutBe = kC, kOutWt = 2 * kC, kOutB = 2 * kC + kC * kC, kOutStride = 3 * kC + kC * kC;
+// packed parameter layout (floats); host side: FourierEmbedding.packed_weights
+//   matrices (chain-packed, 16384 each): [W1_0, W2_0, W1_1, W2_1, ..., Wout]
+//   then per input dim: freq[64], w1_last[128], b1, ln_g, ln_b, b2            (kDimVecs floats)
+//   then to_out: ln_g, ln_b, b                                               (3 * 128)
+constexpr int kVFreq = 0, kVW1Last = 64, kVB1 = 64 + kC, kVG1 = 64 + 2 * kC, kVBe1 = 64 + 3 * kC, kVB2 = 64 + 4 * kC,
+              kDimVecs = 64 + 5 * kC;
+constexpr int kVOutG = 0, kVOutBe = kC, kVOutB = 2 * kC, kOutVecs = 3 * kC;
 
-template <int IN>
-__global__ __launch_bounds__(256) void fourier_kernel(const float *__restrict__ x, const float *__restrict__ extra,
-                                                      int extra_div, const float *__restrict__ pack,
-                                                      float *__restrict__ y, int64_t n_rows, int normalize_out)
+template <int IN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__restrict__ x,
+                                                             const float *__restrict__ extra, int extra_div,
+                                                             const float *__restrict__ pack, float *__restrict__ y,
+                                                             int64_t n_rows, int normalize_out)
 {
-    __shared__ __attribute__((aligned(16))) Smem sm;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row0 = (int64_t)blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
+    const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
+    const bool valid = row < n_rows;
+    const int64_t rowc = valid ? row : n_rows - 1;   // tail lanes recompute the last row; their store is masked
     const float eps = 1e-5f;
-    const float *out_pack = pack + IN * kDimStride;
+    const float *mats = pack;
+    const float *vecs = pack + (size_t)(2 * IN + 1) * kMatFloats;
+    const float *out_vec = vecs + IN * kDimVecs;
 
-    Stream st;
-    st.chunk = 0;
-    prefetch_chunk(st, IN > 0 ? pack + kOffW1t : out_pack + kOutWt, tid);
-
-    if (IN > 0) {
-        // raw inputs of the wave's 32 rows (tail rows clamp to the last valid row; their stores are masked)
-        for (int i = lane; i < IN * kRowsPerWave; i += 64) {
-            const int r = i % kRowsPerWave, d = i / kRowsPerWave;
-            int64_t row = row0 + r;
-            row = row < n_rows ? row : n_rows - 1;
-            sm.x[wave][d][r] = x[row * IN + d];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
+    stage_matrix<WAVES>(mats, buf0, wave, lane);
 
     f32x16 acc_y[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_y[t][r] = 0.f;
+    fill_zero(acc_y);
 
 #pragma unroll 1
     for (int d = 0; d < IN; ++d) {
-        const float *dp = pack + d * kDimStride;
-        // ---- Fourier features into the A tile: k < 64 cos, 64 <= k < 128 sin (reference cat order, :60)
-        {
-            const float xv = sm.x[wave][d][lane & 31];
-            const int fbase = (lane >> 5) * 32;
-#pragma unroll 4
-            for (int j = 0; j < 32; ++j) {
-                const float f = dp[kOffFreq + fbase + j];
+        const float *dv = vecs + d * kDimVecs;
+        const float xv = x[rowc * IN + d];
+        // ---- Fourier features of this lane's 32 frequencies: cos in k-steps 0..31, sin in 32..63
+        f32x16 ft[4];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 f4 = *reinterpret_cast<const f32x4 *>(dv + kVFreq + 32 * h + 4 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int s = 4 * q + j;
                 // ((x * f) * 2) * pi in fp32, the reference's evaluation order (:58)
-                const float ang = __fmul_rn(__fmul_rn(__fmul_rn(xv, f), 2.0f), 3.14159265358979323846f);
+                const float ang = __fmul_rn(__fmul_rn(__fmul_rn(xv, f4[j]), 2.0f), 3.14159265358979323846f);
                 float sn, cs;
                 sincosf(ang, &sn, &cs);
-                sm.a[wave][fbase + j][lane & 31] = cs;
-                sm.a[wave][kF + fbase + j][lane & 31] = sn;
+                ft[s >> 4][s & 15] = cs;
+                ft[2 + (s >> 4)][s & 15] = sn;
             }
         }
         // ---- h = W1 [features, x] + b1 : the 129th input column is a rank-1 term folded into the accumulator init
         f32x16 acc_h[4];
-        {
-            float xr[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) xr[r] = sm.x[wave][d][acc_row(r, lane)];
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int col = 32 * t + (lane & 31);
-                const float b1 = dp[kOffB1 + col], wl = dp[kOffW1Last + col];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dv + kVB1 + 32 * t + 8 * q + 4 * h);
+                const f32x4 wl = *reinterpret_cast<const f32x4 *>(dv + kVW1Last + 32 * t + 8 * q + 4 * h);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc_h[t][r] = fmaf(xr[r], wl, b1);
+                for (int j = 0; j < 4; ++j) acc_h[t][4 * q + j] = fmaf(xv, wl[j], b1[j]);
             }
-        }
-        gemm_pass(acc_h, sm, st, dp + kOffW1t, dp + kOffW2t, wave, lane, tid);
-        row_layer_norm<true, true>(acc_h, dp + kOffG1, dp + kOffBe1, lane, eps);
-        acc_to_tile(acc_h, sm.a[wave], lane);
+        sync_for_stage();
+        gemm<WAVES>(acc_h, ft, buf0, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
+        layer_norm<true, true>(acc_h, dv + kVG1, dv + kVBe1, h, eps);
         // ---- y += W2 h + b2
-        const float *next = (d + 1 < IN) ? pack + (d + 1) * kDimStride + kOffW1t : out_pack + kOutWt;
-        gemm_pass(acc_y, sm, st, dp + kOffW2t, next, wave, lane, tid);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float b2 = dp[kOffB2 + 32 * t + (lane & 31)];
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_y[t][r] += b2;
-        }
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 b2 = *reinterpret_cast<const f32x4 *>(dv + kVB2 + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc_y[t][4 * q + j] += b2[j];
+            }
+        sync_for_stage();
+        gemm<WAVES>(acc_y, acc_h, buf1, lane, mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
     }
 
     if (extra != nullptr) {   // summed categorical embeddings (:65-66)
+        f32x16 e[4];
+        load_row(e, extra, rowc / extra_div, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int64_t row = row0 + acc_row(r, lane);
-            row = (row < n_rows ? row : n_rows - 1) / extra_div;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc_y[t][r] += extra[row * kC + 32 * t + (lane & 31)];
-        }
+        for (int t = 0; t < 4; ++t) acc_y[t] += e[t];
     }
 
     // ---- to_out: LN -> ReLU -> Linear (:67)
-    row_layer_norm<true, true>(acc_y, out_pack + kOutG, out_pack + kOutBe, lane, eps);
-    acc_to_tile(acc_y, sm.a[wave], lane);
+    layer_norm<true, true>(acc_y, out_vec + kVOutG, out_vec + kVOutBe, h, eps);
     f32x16 acc_o[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const float bo = out_pack[kOutB + 32 * t + (lane & 31)];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc_o[t][r] = bo;
-    }
-    gemm_pass(acc_o, sm, st, out_pack + kOutWt, nullptr, wave, lane, tid);
-    if (normalize_out) row_layer_norm<false, false>(acc_o, nullptr, nullptr, lane, eps);
-
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int64_t row = row0 + acc_row(r, lane);
-        if (row < n_rows) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) y[row * kC + 32 * t + (lane & 31)] = acc_o[t][r];
-        }
-    }
+    load_feature_vec(acc_o, out_vec + kVOutB, h);
+    sync_for_stage();
+    gemm<WAVES>(acc_o, acc_y, buf0, lane);
+    if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
+    if (valid) store_row(acc_o, y, row, h);
 }
 
 }  // namespace
 
 extern "C" size_t qcn_fourier_pack_floats(int input_dim)
 {
-    return (size_t)input_dim * kDimStride + kOutStride;
+    return (size_t)(2 * input_dim + 1) * kMatFloats + (size_t)input_dim * kDimVecs + kOutVecs;
 }
 
 extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
@@ -161,19 +127,27 @@ extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float 
     if (!pack || !y || (input_dim > 0 && !x) || (input_dim == 0 && !extra)) return QCN_ERR_INVALID_ARGUMENT;
     if (extra_div < 1 || extra_div > 0x7fffffff) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const unsigned grid = (unsigned)((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
+    const int waves = pick_waves(n_rows);
+    const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC);
     void *token = qcn_prof_begin(QCN_PROF_FOURIER, flops, s);
-#define QCN_LAUNCH_FOURIER(IN)                                                                                   \
-    hipLaunchKernelGGL((fourier_kernel<IN>), dim3(grid), dim3(256), 0, s, x, extra, (int)extra_div, pack, y, n_rows, \
+#define QCN_LAUNCH_FOURIER(IN, W)                                                                                    \
+    hipLaunchKernelGGL((fourier_kernel<IN, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, n_rows, \
                        normalize_out)
+#define QCN_LAUNCH_FOURIER_W(IN)                                                                                     \
+    do {                                                                                                             \
+        if (waves == 8) QCN_LAUNCH_FOURIER(IN, 8);                                                                   \
+        else if (waves == 4) QCN_LAUNCH_FOURIER(IN, 4);                                                              \
+        else QCN_LAUNCH_FOURIER(IN, 2);                                                                              \
+    } while (0)
     switch (input_dim) {
-    case 0: QCN_LAUNCH_FOURIER(0); break;
-    case 1: QCN_LAUNCH_FOURIER(1); break;
-    case 2: QCN_LAUNCH_FOURIER(2); break;
-    case 3: QCN_LAUNCH_FOURIER(3); break;
-    default: QCN_LAUNCH_FOURIER(4); break;
+    case 0: QCN_LAUNCH_FOURIER_W(0); break;
+    case 1: QCN_LAUNCH_FOURIER_W(1); break;
+    case 2: QCN_LAUNCH_FOURIER_W(2); break;
+    case 3: QCN_LAUNCH_FOURIER_W(3); break;
+    default: QCN_LAUNCH_FOURIER_W(4); break;
     }
+#undef QCN_LAUNCH_FOURIER_W
 #undef QCN_LAUNCH_FOURIER
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);

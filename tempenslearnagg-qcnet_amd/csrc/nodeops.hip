@@ -7,87 +7,94 @@
 //                        x1 = x + LN_post(W_out u + b_out)                                        (:119, :83)
 //                        out = x1 + LN_ffpost(W_2 relu(W_1 LN_ffpre(x1) + b_1) + b_2)             (:84, :121-122)
 //
-// Both use the row-tile machinery of mfma_tile.hip.h: a wave owns 32 complete rows, every LayerNorm / sigmoid / residual
-// is an in-register epilogue, the 512-wide FFN hidden layer is produced and consumed in four 128-wide blocks and never
-// leaves the CU.  HBM traffic per row: reads of agg, xn, s, x and one write (2.5 KiB) against 11 x 32 KiB of flops:
-// MFMA-bound (fp32 matrix cores, exact fp32 fma chains).
-#include "mfma_tile.hip.h"
+// Both run on the feature-major chain machinery of chain_tile.hip.h: a lane owns one row, a layer's output registers
+// are the next layer's MFMA operand, LDS holds only the double-buffered packed weights (LDS-DMA staged), every
+// LayerNorm / sigmoid / residual is an in-lane epilogue, the 512-wide FFN hidden layer is produced and consumed in
+// four 128-wide blocks and never leaves the registers.  HBM traffic per row: reads of agg, xn, s, x and one write
+// (2.5 KiB) against 11 x 32 KiB of flops: MFMA-bound (fp32 matrix cores, exact fp32 fma chains).
+#include "chain_tile.hip.h"
 
 namespace {
 
-using namespace qcn_tile;
+using namespace qcn_chain;
 
-constexpr int kMat = kC * kC;
-
-__global__ __launch_bounds__(256) void ln_linear_kernel(const float *__restrict__ x, int64_t n_rows,
-                                                        const float *__restrict__ ln_g, const float *__restrict__ ln_b,
-                                                        const float *__restrict__ wt, const float *__restrict__ bias,
-                                                        int n_out, float *__restrict__ y0, float *__restrict__ y1,
-                                                        float *__restrict__ y2, float *__restrict__ y3,
-                                                        float *__restrict__ xn_out)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__restrict__ x, int64_t n_rows,
+                                                               const float *__restrict__ ln_g,
+                                                               const float *__restrict__ ln_b,
+                                                               const float *__restrict__ wp,
+                                                               const float *__restrict__ bias, int n_out,
+                                                               float *__restrict__ y0, float *__restrict__ y1,
+                                                               float *__restrict__ y2, float *__restrict__ y3,
+                                                               float *__restrict__ xn_out)
 {
-    __shared__ __attribute__((aligned(16))) Smem sm;
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row0 = (int64_t)blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
-    Stream st;
-    st.chunk = 0;
-    prefetch_chunk(st, wt, tid);
+    const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
+    const bool valid = row < n_rows;
+    const int64_t rowc = valid ? row : n_rows - 1;
 
+    stage_matrix<WAVES>(wp, wlds, wave, lane);
     f32x16 xv[4];
-    load_rows(xv, x, row0, n_rows, lane);
-    if (ln_g != nullptr) row_layer_norm<true, false>(xv, ln_g, ln_b, lane, 1e-5f);
-    if (xn_out != nullptr) store_rows(xv, xn_out, row0, n_rows, lane);
-    acc_to_tile(xv, sm.a[wave], lane);
+    load_row(xv, x, rowc, h);
+    if (ln_g != nullptr) layer_norm<true, false>(xv, ln_g, ln_b, h, 1e-5f);
+    if (xn_out != nullptr && valid) store_row(xv, xn_out, row, h);
 #pragma unroll 1
     for (int j = 0; j < n_out; ++j) {
         f32x16 acc[4];
-        fill_cols(acc, bias ? bias + j * kC : nullptr, lane);
-        gemm_pass(acc, sm, st, wt + (size_t)j * kMat, j + 1 < n_out ? wt + (size_t)(j + 1) * kMat : nullptr, wave, lane,
-                  tid);
+        if (bias != nullptr) load_feature_vec(acc, bias + j * kC, h);
+        else fill_zero(acc);
+        sync_for_stage();   // matrix j has landed (every wave drained its DMA), buffer (j+1)&1 is no longer read
+        gemm<WAVES>(acc, xv, wlds + (j & 1) * kMatVec4, lane, j + 1 < n_out ? wp + (size_t)(j + 1) * kMatFloats : nullptr,
+                    wlds + ((j + 1) & 1) * kMatVec4, wave);
         float *y = j == 0 ? y0 : j == 1 ? y1 : j == 2 ? y2 : y3;
-        store_rows(acc, y, row0, n_rows, lane);
+        if (valid) store_row(acc, y, row, h);
     }
 }
 
-// pack: 11 k-major matrices in consumption order [Wg_agg, Wg_x, Wout, W1_0, W2_0, W1_1, W2_1, W1_2, W2_2, W1_3, W2_3]
-// then vectors [bg, bout, lnpost_g, lnpost_b, lnffpre_g, lnffpre_b, b1 (512), b2, lnffpost_g, lnffpost_b]
+// pack: 11 chain-packed matrices in consumption order [Wg_agg, Wg_x, Wout, W1_0, W2_0, W1_1, W2_1, W1_2, W2_2, W1_3, W2_3]
+// then plain vectors [bg, bout, lnpost_g, lnpost_b, lnffpre_g, lnffpre_b, b1 (512), b2, lnffpost_g, lnffpost_b]
 constexpr int kPostMats = 11;
 constexpr int kVBg = 0, kVBout = kC, kVLpG = 2 * kC, kVLpB = 3 * kC, kVLfG = 4 * kC, kVLfB = 5 * kC, kVB1 = 6 * kC,
               kVB2 = 10 * kC, kVLqG = 11 * kC, kVLqB = 12 * kC, kPostVecs = 13 * kC;
 
-__global__ __launch_bounds__(256) void attn_post_kernel(const float *__restrict__ agg, const float *__restrict__ xn,
-                                                        const float *__restrict__ s, const float *__restrict__ xres,
-                                                        const float *__restrict__ pack, int64_t n_rows,
-                                                        float *__restrict__ out)
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__restrict__ agg,
+                                                               const float *__restrict__ xn,
+                                                               const float *__restrict__ s,
+                                                               const float *__restrict__ xres,
+                                                               const float *__restrict__ pack, int64_t n_rows,
+                                                               float *__restrict__ out)
 {
-    __shared__ __attribute__((aligned(16))) Smem sm;
-    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row0 = (int64_t)blockIdx.x * kRowsPerBlock + wave * kRowsPerWave;
+    const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
+    const bool valid = row < n_rows;
+    const int64_t rowc = valid ? row : n_rows - 1;
     const float *mats = pack;
-    const float *vec = pack + (size_t)kPostMats * kMat;
+    const float *vec = pack + (size_t)kPostMats * kMatFloats;
     const float eps = 1e-5f;
-    Stream st;
-    st.chunk = 0;
-    prefetch_chunk(st, mats, tid);
 
+    stage_matrix<WAVES>(mats, buf0, wave, lane);
     // ---- gate: g = sigmoid(Wg [agg, xn] + bg)
     f32x16 va[4], acc[4];
-    load_rows(va, agg, row0, n_rows, lane);
-    acc_to_tile(va, sm.a[wave], lane);
-    fill_cols(acc, vec + kVBg, lane);
-    gemm_pass(acc, sm, st, mats, mats + kMat, wave, lane, tid);
+    load_row(va, agg, rowc, h);
+    load_feature_vec(acc, vec + kVBg, h);
+    sync_for_stage();
+    gemm<WAVES>(acc, va, buf0, lane, mats + kMatFloats, buf1, wave);
     {
         f32x16 vx[4];
-        load_rows(vx, xn, row0, n_rows, lane);
-        acc_to_tile(vx, sm.a[wave], lane);
+        load_row(vx, xn, rowc, h);
+        sync_for_stage();
+        gemm<WAVES>(acc, vx, buf1, lane, mats + 2 * kMatFloats, buf0, wave);
     }
-    gemm_pass(acc, sm, st, mats + kMat, mats + 2 * kMat, wave, lane, tid);
     // ---- u = agg + g * (s - agg)
     {
         f32x16 vs[4];
-        load_rows(vs, s, row0, n_rows, lane);
+        load_row(vs, s, rowc, h);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -96,44 +103,45 @@ __global__ __launch_bounds__(256) void attn_post_kernel(const float *__restrict_
                 va[t][r] = fmaf(g, vs[t][r] - va[t][r], va[t][r]);
             }
     }
-    acc_to_tile(va, sm.a[wave], lane);
-    // ---- x1 = x + LN_post(Wout u + bout)
-    fill_cols(acc, vec + kVBout, lane);
-    gemm_pass(acc, sm, st, mats + 2 * kMat, mats + 3 * kMat, wave, lane, tid);
-    row_layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, lane, eps);
+    // ---- x1 = x + LN_post(Wout u + bout); parked in `out` until the last residual
+    load_feature_vec(acc, vec + kVBout, h);
+    sync_for_stage();
+    gemm<WAVES>(acc, va, buf0, lane, mats + 3 * kMatFloats, buf1, wave);
+    layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
     f32x16 x1[4];
-    load_rows(x1, xres, row0, n_rows, lane);
+    load_row(x1, xres, rowc, h);
 #pragma unroll
     for (int t = 0; t < 4; ++t) x1[t] += acc[t];
+    if (valid) store_row(x1, out, row, h);
     // ---- feed-forward block, hidden layer in four 128-wide blocks
-    f32x16 xn1[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) xn1[t] = x1[t];
-    row_layer_norm<true, false>(xn1, vec + kVLfG, vec + kVLfB, lane, eps);
+    layer_norm<true, false>(x1, vec + kVLfG, vec + kVLfB, h, eps);
     f32x16 acc_o[4];
-    fill_cols(acc_o, vec + kVB2, lane);
+    load_feature_vec(acc_o, vec + kVB2, h);
 #pragma unroll 1
     for (int hb = 0; hb < 4; ++hb) {
-        const float *w1 = mats + (size_t)(3 + 2 * hb) * kMat;
-        acc_to_tile(xn1, sm.a[wave], lane);
-        fill_cols(acc, vec + kVB1 + hb * kC, lane);
-        gemm_pass(acc, sm, st, w1, w1 + kMat, wave, lane, tid);
+        const float *w1 = mats + (size_t)(3 + 2 * hb) * kMatFloats;
+        load_feature_vec(acc, vec + kVB1 + hb * kC, h);
+        sync_for_stage();
+        gemm<WAVES>(acc, x1, buf1, lane, w1 + kMatFloats, buf0, wave);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
-        acc_to_tile(acc, sm.a[wave], lane);
-        gemm_pass(acc_o, sm, st, w1 + kMat, hb < 3 ? w1 + 2 * kMat : nullptr, wave, lane, tid);
+        sync_for_stage();
+        gemm<WAVES>(acc_o, acc, buf0, lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
     }
-    row_layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, lane, eps);
+    layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, h, eps);
+    if (valid) {
+        load_row(x1, out, row, h);   // the lane's own earlier store
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc_o[t] += x1[t];
-    store_rows(acc_o, out, row0, n_rows, lane);
+        for (int t = 0; t < 4; ++t) acc_o[t] += x1[t];
+        store_row(acc_o, out, row, h);
+    }
 }
 
 }  // namespace
 
-extern "C" size_t qcn_attn_post_pack_floats(void) { return (size_t)kPostMats * kMat + kPostVecs; }
+extern "C" size_t qcn_attn_post_pack_floats(void) { return (size_t)kPostMats * kMatFloats + kPostVecs; }
 
 extern "C" int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
                                  const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
@@ -144,10 +152,16 @@ extern "C" int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln
     if (!x || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2) || (n_out > 3 && !y3)) return QCN_ERR_INVALID_ARGUMENT;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const unsigned grid = (unsigned)((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
-    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * n_out * 2.0 * kMat, s);
-    hipLaunchKernelGGL(ln_linear_kernel, dim3(grid), dim3(256), 0, s, x, n_rows, ln_weight, ln_bias, wt, bias, n_out, y0,
-                       y1, y2, y3, xn_out);
+    const int waves = pick_waves(n_rows);
+    const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * n_out * 2.0 * kMatFloats, s);
+#define QCN_LAUNCH(W)                                                                                              \
+    hipLaunchKernelGGL((ln_linear_kernel<W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, ln_weight, ln_bias, wt, bias, \
+                       n_out, y0, y1, y2, y3, xn_out)
+    if (waves == 8) QCN_LAUNCH(8);
+    else if (waves == 4) QCN_LAUNCH(4);
+    else QCN_LAUNCH(2);
+#undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
@@ -159,10 +173,18 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
     if (n_rows < 0) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows == 0) return QCN_OK;
     if (!agg || !xn_dst || !s_proj || !x_res || !pack || !out) return QCN_ERR_INVALID_ARGUMENT;
+    if (out == agg || out == xn_dst || out == s_proj || out == x_res) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const unsigned grid = (unsigned)((n_rows + kRowsPerBlock - 1) / kRowsPerBlock);
-    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * kPostMats * 2.0 * kMat, s);
-    hipLaunchKernelGGL(attn_post_kernel, dim3(grid), dim3(256), 0, s, agg, xn_dst, s_proj, x_res, pack, n_rows, out);
+    const int waves = pick_waves(n_rows);
+    const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * kPostMats * 2.0 * kMatFloats, s);
+#define QCN_LAUNCH(W)                                                                                             \
+    hipLaunchKernelGGL((attn_post_kernel<W>), dim3(grid), dim3(64 * W), 0, s, agg, xn_dst, s_proj, x_res, pack, n_rows, \
+                       out)
+    if (waves == 8) QCN_LAUNCH(8);
+    else if (waves == 4) QCN_LAUNCH(4);
+    else QCN_LAUNCH(2);
+#undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;

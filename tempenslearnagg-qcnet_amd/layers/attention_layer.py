@@ -83,7 +83,7 @@ class AttentionLayer(nn.Module):
 
     def _kernel_packs(self):
         """All parameters in the layouts the kernels consume (include/qcnet_hip.h), cached per parameter version:
-        ``pre_*``: k-major projection stacks for qcn_ln_linear_f32; ``post``: qcn_attn_post_f32 pack;
+        ``pre_*``: chain-packed projection stacks for qcn_ln_linear_f32; ``post``: qcn_attn_post_f32 pack;
         ``pos``: (wk, wv, bv) for qcn_attn_fused_f32 with the attn_prenorm_r affine folded in
         (wk = to_k_r.weight * gamma, wv = to_v_r.weight * gamma, bv = to_v_r.weight @ beta + to_v_r.bias)."""
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -92,7 +92,7 @@ class AttentionLayer(nn.Module):
         C = ops.C
         with torch.no_grad():
             zero = torch.zeros(C, device=self.to_q.weight.device)
-            t = lambda lin: lin.weight.t().contiguous()
+            t = lambda lin: ops.pack_chain_matrix(lin.weight)
             packs = {}
             packs['pre_src'] = (torch.stack([t(self.to_k), t(self.to_v)]).contiguous(),
                                 torch.stack([zero, self.to_v.bias]).contiguous())
@@ -100,10 +100,11 @@ class AttentionLayer(nn.Module):
                                 torch.stack([self.to_q.bias, self.to_s.bias]).contiguous())
             packs['pre_all'] = (torch.stack([t(self.to_q), t(self.to_k), t(self.to_v), t(self.to_s)]).contiguous(),
                                 torch.stack([self.to_q.bias, zero, self.to_v.bias, self.to_s.bias]).contiguous())
-            mats = [self.to_g.weight[:, :C].t(), self.to_g.weight[:, C:].t(), self.to_out.weight.t()]
+            mats = [self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_out.weight]
             w1, w2 = self.ff_mlp[0], self.ff_mlp[3]
             for hb in range(4):
-                mats += [w1.weight[hb * C:(hb + 1) * C, :].t(), w2.weight[:, hb * C:(hb + 1) * C].t()]
+                mats += [w1.weight[hb * C:(hb + 1) * C, :], w2.weight[:, hb * C:(hb + 1) * C]]
+            mats = [ops.pack_chain_matrix(m) for m in mats]
             vecs = [self.to_g.bias, self.to_out.bias, self.attn_postnorm.weight, self.attn_postnorm.bias,
                     self.ff_prenorm.weight, self.ff_prenorm.bias, w1.bias, w2.bias, self.ff_postnorm.weight,
                     self.ff_postnorm.bias]

@@ -3,7 +3,7 @@
 The forward is ONE HIP kernel (``qcn_fourier_embed_f32``): Fourier features, the per-dimension MLPs with their
 LayerNorms, the sum with the categorical embeddings and ``to_out`` are fused, with the contractions on the fp32 matrix
 cores.  The nn.Linear / nn.LayerNorm sub-modules only hold the parameters (reference names); their weights are packed
-into the kernel's k-major layout once and re-packed when a parameter changes.
+into the kernel's chain layout once and re-packed when a parameter changes.
 """
 from typing import List, Optional
 
@@ -47,16 +47,23 @@ class FourierEmbedding(nn.Module):
         params = list(self.parameters())
         key = tuple((p.data_ptr(), p._version) for p in params)
         if key != self._pack_key:
-            parts = []
+            mats, vecs = [], []
             with torch.no_grad():
+                nf = 2 * self.num_freq_bands
+                # k-step s of the first layer takes, from lane half h, cos (s < 32) or sin (s >= 32) of frequency
+                # 32 h + (s mod 32): input column 32 h + s resp. 64 + 32 h + (s - 32) of the reference's cat order
+                s_idx = torch.arange(64).unsqueeze(1)
+                h_idx = torch.arange(2).unsqueeze(0)
+                first_layer_order = torch.where(s_idx < 32, 32 * h_idx + s_idx, 64 + 32 * h_idx + (s_idx - 32))
                 for i in range(self.input_dim):
                     lin1, ln, _, lin2 = self.mlps[i]
-                    nf = 2 * self.num_freq_bands
-                    parts += [self.freqs.weight[i], lin1.weight[:, :nf].t().reshape(-1), lin1.weight[:, nf], lin1.bias,
-                              ln.weight, ln.bias, lin2.weight.t().reshape(-1), lin2.bias]
+                    mats += [ops.pack_chain_matrix(lin1.weight[:, :nf], first_layer_order),
+                             ops.pack_chain_matrix(lin2.weight)]
+                    vecs += [self.freqs.weight[i], lin1.weight[:, nf], lin1.bias, ln.weight, ln.bias, lin2.bias]
                 ln, _, lin = self.to_out
-                parts += [ln.weight, ln.bias, lin.weight.t().reshape(-1), lin.bias]
-                self._pack = torch.cat([p.reshape(-1).float() for p in parts]).contiguous()
+                mats.append(ops.pack_chain_matrix(lin.weight))
+                vecs += [ln.weight, ln.bias, lin.bias]
+                self._pack = torch.cat([p.reshape(-1).float() for p in mats + vecs]).contiguous()
             self._pack_key = key
         return self._pack
 

@@ -147,6 +147,41 @@ def row_normalize(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     return y
 
 
+_CHAIN_INDEX = {}
+
+
+def chain_feature_order(device=None) -> torch.Tensor:
+    """[64, 2] long: the input feature that k-step ``s`` of the feature-major MFMA chain takes from lane half ``h``
+    (csrc/chain_tile.hip.h: element (t, r) of a row vector is feature 32 t + (r & 3) + 8 (r >> 2) + 4 h, s = 16 t + r)."""
+    s = torch.arange(64).unsqueeze(1)
+    h = torch.arange(2).unsqueeze(0)
+    r = s & 15
+    return (32 * (s >> 4) + (r & 3) + 8 * (r >> 2) + 4 * h).to(device)
+
+
+def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A ``nn.Linear(128, 128).weight`` ([out, in]) in the order the chain kernels consume it:
+    ``P[s, lane, t] = weight[32 t + (lane & 31), in_index[s, lane >> 5]]`` flattened to 16384 floats.  ``in_index``
+    defaults to :func:`chain_feature_order` (the operand is a register-resident row vector)."""
+    if tuple(weight.shape) != (C, C):
+        raise ValueError('pack_chain_matrix expects a [128, 128] weight, got %s' % (tuple(weight.shape),))
+    dev = weight.device
+    if in_index is None:
+        key = str(dev)
+        if key not in _CHAIN_INDEX:
+            _CHAIN_INDEX[key] = chain_feature_order(dev)
+        in_index = _CHAIN_INDEX[key]
+    out_index = (32 * torch.arange(4, device=dev).view(1, 4) + torch.arange(32, device=dev).view(32, 1))  # [m, t]
+    # P[s, h, m, t]
+    packed = weight.detach().float()[out_index.view(1, 1, 32, 4), in_index.to(dev).view(64, 2, 1, 1)]
+    return packed.reshape(-1).contiguous()
+
+
+def pack_chain_matrices(weights) -> torch.Tensor:
+    """Stack of chain-packed matrices, [len(weights), 16384]."""
+    return torch.stack([pack_chain_matrix(w) for w in weights]).contiguous()
+
+
 def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor, extra: Optional[torch.Tensor] = None,
                   extra_div: int = 1, normalize_out: bool = False, n_rows: Optional[int] = None) -> torch.Tensor:
     """qcn_fourier_embed_f32: the whole FourierEmbedding forward; ``pack`` from ``pack_fourier_weights``."""
@@ -172,12 +207,12 @@ def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor,
 def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], wt: torch.Tensor,
               bias: Optional[torch.Tensor], want_xn: bool = False):
     """qcn_ln_linear_f32: ([y_0 .. y_{n_out-1}], xn or None) with y_j = W_j LayerNorm(x) + b_j; ``wt`` is the stack
-    of k-major (transposed) weights [n_out, 128, 128], ``bias`` [n_out, 128] or None."""
+    of chain-packed weights [n_out, 16384] (:func:`pack_chain_matrices`), ``bias`` [n_out, 128] or None."""
     dev = x.device
     n = x.size(0)
     n_out = wt.size(0)
     _require(x, 'x', torch.float32, dev, (n, C))
-    _require(wt, 'wt', torch.float32, dev, (n_out, C, C))
+    _require(wt, 'wt', torch.float32, dev, (n_out, C * C))
     if not 1 <= n_out <= 4:
         raise ValueError('n_out must be 1..4')
     if bias is not None:
@@ -210,7 +245,7 @@ def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_r
 def gru_last_hidden(x_seq: torch.Tensor, n_steps: int, wih_t: torch.Tensor, b_ih: torch.Tensor, whh_t: torch.Tensor,
                     b_hh: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
     """Final hidden state of a 1-layer GRU(128, 128) over ``n_steps`` steps.  ``x_seq`` [n_seq * n_steps, 128] with
-    row = seq * n_steps + t; ``wih_t`` [3, 128, 128] k-major per gate (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` [128, 384];
+    row = seq * n_steps + t; ``wih_t`` [3, 16384] chain-packed per gate (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` [128, 384];
     ``b_hh`` [384]; ``h0`` [128].  Input half: one qcn_ln_linear_f32 launch; recurrence: one qcn_gru_f32 launch."""
     dev = x_seq.device
     _require(x_seq, 'x_seq', torch.float32, dev, (None, C))

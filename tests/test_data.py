@@ -53,3 +53,26 @@ def test_make_batch_ids_are_disjoint_across_ranks():
     a = make_batch([0, 1], **SCENE_TINY)
     b = make_batch([2, 3], **SCENE_TINY)
     assert not torch.equal(a['agent']['position'], b['agent']['position'])
+
+
+def test_pack_chain_matrix_is_a_permutation_that_keeps_the_linear_map():
+    """ops.pack_chain_matrix: P[s, h, m, t] = W[32 t + m, kin(s, h)] — contracting the packed weights with a row vector
+    held in the kernels' register order gives W x (include/qcnet_hip.h, 'Chain-packed 128x128 matrix')."""
+    from tempenslearnagg_qcnet_amd import ops
+    torch.manual_seed(3)
+    w = torch.randn(128, 128)
+    x = torch.randn(128)
+    order = ops.chain_feature_order()
+    assert sorted(order.reshape(-1).tolist()) == list(range(128))
+    p = ops.pack_chain_matrix(w).view(64, 2, 32, 4)
+    y = torch.einsum('shmt,sh->mt', p.double(), x[order].double())          # [m, t] -> out feature 32 t + m
+    ref = (w.double() @ x.double()).view(4, 32).t()
+    assert torch.allclose(y, ref, atol=1e-12)
+    # first layer of a Fourier MLP: cos | sin k order
+    s_idx = torch.arange(64).unsqueeze(1)
+    h_idx = torch.arange(2).unsqueeze(0)
+    first = torch.where(s_idx < 32, 32 * h_idx + s_idx, 64 + 32 * h_idx + (s_idx - 32))
+    assert sorted(first.reshape(-1).tolist()) == list(range(128))
+    p1 = ops.pack_chain_matrix(w, first).view(64, 2, 32, 4)
+    y1 = torch.einsum('shmt,sh->mt', p1.double(), x[first].double())
+    assert torch.allclose(y1, ref, atol=1e-12)

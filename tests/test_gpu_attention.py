@@ -208,7 +208,7 @@ def test_gru_kernel_matches_torch_gru():
     with torch.no_grad():
         want = gru(seq, h0.view(1, 1, 128).repeat(1, n_seq, 1))[1].squeeze(0)
     x = seq.transpose(0, 1).reshape(-1, 128).contiguous().to(DEV)          # row = seq * n_steps + t
-    wih_t = gru.weight_ih_l0.detach().view(3, 128, 128).transpose(1, 2).contiguous().to(DEV)
+    wih_t = ops.pack_chain_matrices(list(gru.weight_ih_l0.detach().view(3, 128, 128).to(DEV)))
     got = ops.gru_last_hidden(x, n_steps, wih_t, gru.bias_ih_l0.detach().view(3, 128).contiguous().to(DEV),
                               gru.weight_hh_l0.detach().t().contiguous().to(DEV), gru.bias_hh_l0.detach().to(DEV),
                               h0.to(DEV))
