@@ -11,21 +11,31 @@
 // Algorithmic HBM bytes: 512*E_base (rhat) + 8*E_base (col, eid) + gathers of k/v (cache-served) + 1 KiB per
 // destination (q in, out) — SURVEY.md §8(d) "r-projection fused" row: 1552*E + 1024*n_dst.
 //
-// Mapping: one wave64 per destination, lane l owns channels 2l, 2l+1 (head = l >> 3).  16 waves (1024 threads) per
-// workgroup, one workgroup per CU: W_kr*gamma and W_vr*gamma (64 KiB each) live in LDS for the workgroup's lifetime,
-// XOR-swizzled at 8-byte granularity so that both the row read of the prologue and the 16-row column-slice read of the
-// epilogue are bank-conflict free.  Mode replication of the decoder (qcnet_decoder.py:190-192,208-211: the K mode
-// queries of an agent share one edge list and one r) is expressed by `rep`/`layout`: consecutive waves take the K modes
-// of one CSR row, so rhat_e is fetched from HBM once and served to the other K-1 waves from L1/L2.
+// Mapping: one wave64 per destination.  Lane = 8 h + sub: head h, and
+//   * for k / v / q / out the lane owns channels 2 lane, 2 lane + 1 (they belong to head h: coalesced 512-B row reads),
+//   * for the 8 x 128 positional state (utilde^h, s^h) the lane owns the 16-channel slice 16 sub .. 16 sub + 15 of ITS
+//     head: the per-edge logit is 16 in-lane FMAs + a 3-step DPP sum over the 8 lanes of the head, the weighted sum of
+//     rhat 16 in-lane FMAs with the lane's own softmax weight — no cross-head traffic at all.  The rhat row is read
+//     from HBM once, coalesced, and handed to the slice owners through a per-wave 512-B LDS row (one ds_write_b64 +
+//     four broadcast ds_read_b128 per lane and edge).
+// 16 waves (1024 threads) per workgroup, one workgroup per CU: W_kr*gamma and W_vr*gamma (64 KiB each) live in LDS for
+// the workgroup's lifetime.  All LDS rows are stored in 16-byte chunks with chunk c of row o at c ^ (2 ((o >> 4) & 1) +
+// (c >> 4)): the slice reads of 16 consecutive lanes (two heads x eight slices) then fall on 16 distinct bank groups.
+// Rows and indices are requested one resp. two iterations ahead of their use.  Mode replication of the decoder
+// (qcnet_decoder.py:190-192,208-211: the K mode queries of an agent share one edge list and one r) is expressed by
+// `rep`/`layout`: consecutive waves take the K modes of one CSR row, so rhat_e is fetched from HBM once and served
+// to the other K-1 waves from L1/L2.
 #include "common.hip.h"
 
 namespace {
 
 constexpr int kC = QCN_CHANNELS;       // 128
-constexpr int kH = QCN_HEADS;          // 8
+
 constexpr int kWaves = 16;
-constexpr int kUnroll = 4;
+constexpr int kU = 2;                  // edges per iteration
 constexpr float kLog2e = 1.4426950408889634f;
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -33,34 +43,17 @@ __device__ __forceinline__ float dpp_mov(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 
+constexpr int kDppXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kDppMirror8 = 0x141;     // row_half_mirror: lane i <-> 7 - i inside every group of 8
+
+// sum over the 8 lanes of a head
 __device__ __forceinline__ float head_sum(float v)
 {
-    v += dpp_mov<0xB1>(v);    // quad_perm [1,0,3,2]
-    v += dpp_mov<0x4E>(v);    // quad_perm [2,3,0,1]
-    v += dpp_mov<0x141>(v);   // row_half_mirror
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppMirror8>(v);
     return v;
-}
-
-__device__ __forceinline__ float bcast_lane(float v, int lane)   // lane is a compile-time constant at every call
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
-
-// Pairwise exchange-and-add across the two wave halves: afterwards lanes 0-31 hold (x summed over the lane pair
-// l, l+32) and lanes 32-63 hold (y summed over the pair).
-// (Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc 7.2 folds the builtin's two results into one register
-// when both are consumed by one add — verified on the box, scripts/dbg/butterfly.hip.  The s_nop covers the
-// VALU-write -> permlane-read hazard, which nothing pads inside an asm string.)
-__device__ __forceinline__ float fold32(float x, float y)
-{
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-// Same across the 16-lane rows: even rows end with x (pair l, l+16), odd rows with y.
-__device__ __forceinline__ float fold16(float x, float y)
-{
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));
-    return x + y;
 }
 
 __device__ __forceinline__ void wave_lds_fence()
@@ -88,25 +81,64 @@ struct FusedArgs {
     int group_rows, group_row_shift, group_col_shift, group_src_stride;
 };
 
+struct EdgeRows {
+    float2 k[kU], v[kU], r[kU];
+};
+
+template <bool HAS_EID>
+__device__ __forceinline__ void load_indices(const FusedArgs &a, int j, int end, int src_off, int (&src)[kU], int (&e)[kU])
+{
+#pragma unroll
+    for (int t = 0; t < kU; ++t) {
+        const int jj = min(j + t, end - 1);           // clamp, masked at the use (no per-load branches)
+        src[t] = a.col[jj] + src_off;
+        e[t] = HAS_EID ? a.eid[jj] : jj;
+    }
+}
+
+__device__ __forceinline__ void load_rows(const FusedArgs &a, const int (&src)[kU], const int (&e)[kU], int lane, EdgeRows &r)
+{
+#pragma unroll
+    for (int t = 0; t < kU; ++t) {
+        r.k[t] = ld2(a.k, src[t], lane);
+        r.v[t] = ld2(a.v, src[t], lane);
+        r.r[t] = ld2(a.rhat, e[t], lane);
+    }
+}
+
 template <bool HAS_EID>
 __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
 {
-    // [o][slot ^ (o & 15)] with slot = channel pair; 64 KiB each
-    __shared__ __attribute__((aligned(16))) float2 s_wk[kC][64];
-    __shared__ __attribute__((aligned(16))) float2 s_wv[kC][64];
-    __shared__ __attribute__((aligned(16))) float2 s_vec[kWaves][64];    // per-wave s^h staging
-    __shared__ __attribute__((aligned(16))) float s_out[kWaves][kC];     // per-wave projected output
+    // one array (see the chunk swizzle above): [0, 128) rows of wk, [128, 256) rows of wv, then kU staging rows per wave
+    __shared__ __attribute__((aligned(16))) float lds[(2 * kC + kWaves * kU) * kC];
+    float *const s_wk = lds, *const s_wv = lds + kC * kC;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 3, sub = lane & 7;
+    float *const s_stage = lds + (2 * kC + wave * kU) * kC;
 
-    for (int i = tid; i < kC * 64; i += 1024) {
-        const int o = i >> 6, slot = i & 63;
-        s_wk[o][slot ^ (o & 15)] = *reinterpret_cast<const float2 *>(a.wk + o * kC + 2 * slot);
-        s_wv[o][slot ^ (o & 15)] = *reinterpret_cast<const float2 *>(a.wv + o * kC + 2 * slot);
+    for (int i = tid; i < kC * 32; i += 1024) {
+        const int o = i >> 5, c = i & 31;
+        const int pc = c ^ (2 * ((o >> 4) & 1) + (c >> 4));
+        *reinterpret_cast<f32x4 *>(s_wk + o * kC + 4 * pc) = *reinterpret_cast<const f32x4 *>(a.wk + o * kC + 4 * c);
+        *reinterpret_cast<f32x4 *>(s_wv + o * kC + 4 * pc) = *reinterpret_cast<const f32x4 *>(a.wv + o * kC + 4 * c);
     }
     __syncthreads();
+
+    // per-lane LDS offsets (floats).  Slice chunk i of a weight row of this lane's head / of a staging row:
+    int w_off[4], r_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        w_off[i] = 16 * h * kC + 4 * ((4 * sub + i) ^ (2 * (h & 1) + (sub >> 2)));
+        r_off[i] = 4 * ((4 * sub + i) ^ (sub >> 2));
+    }
+    // this lane's own channel pair inside a staging row (writer side), and the head's 16 q values (reader side)
+    const int st_off = 4 * ((lane >> 1) ^ (lane >> 5)) + 2 * (lane & 1);
+    int q_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q_off[i] = 4 * ((4 * h + i) ^ (h >> 2));
 
     // contiguous chunk of destinations per workgroup (XCD-contiguous through the block remap)
     const int64_t nb = gridDim.x;
@@ -115,7 +147,7 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
     const int64_t begin = lb * per;
     const int64_t end_idx = begin + per < a.n_dst ? begin + per : a.n_dst;
     const float2 bias = ld2(a.bv, 0, lane);
-    const int d16 = lane & 15, quarter = lane >> 4;
+    const bool b0 = (sub & 1) != 0, b1 = (sub & 2) != 0, b2 = (sub & 4) != 0;
 
     for (int64_t idx = begin + wave; idx < end_idx; idx += kWaves) {
         int64_t row = idx, node = idx;
@@ -134,114 +166,126 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
 
         float m = -INFINITY, l = 0.f;
         float2 accv = make_float2(0.f, 0.f);
-        float2 s[kH];
-#pragma unroll
-        for (int h = 0; h < kH; ++h) s[h] = make_float2(0.f, 0.f);
+        float2 proj = make_float2(0.f, 0.f);
 
         if (end > beg) {
-            // ---- prologue: utilde^h[c] = sum_d wk[16h + d][c] * q'^h[d] for this lane's two channels
-            float2 u[kH];
+            int src[kU], e[kU];
+            EdgeRows cur, nxt;
+            load_indices<HAS_EID>(a, beg, end, src_off, src, e);
+            load_rows(a, src, e, lane, cur);
+            load_indices<HAS_EID>(a, beg + kU, end, src_off, src, e);
+
+            // ---- prologue: utilde^h[c] = sum_d wk[16h + d][c] * q'^h[d] for the lane's 16-channel slice
+            *reinterpret_cast<float2 *>(s_stage + st_off) = qv;
+            wave_lds_fence();
+            float qh[16];
 #pragma unroll
-            for (int h = 0; h < kH; ++h) {
-                float ux = 0.f, uy = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4 *>(s_stage + q_off[i]);
 #pragma unroll
-                for (int dp = 0; dp < 8; ++dp) {
-                    const float qa = bcast_lane(qv.x, 8 * h + dp), qb = bcast_lane(qv.y, 8 * h + dp);
-                    const int o0 = 16 * h + 2 * dp, o1 = o0 + 1;
-                    const float2 wa = s_wk[o0][lane ^ (o0 & 15)], wb = s_wk[o1][lane ^ (o1 & 15)];
-                    ux = fmaf(wa.x, qa, ux); uy = fmaf(wa.y, qa, uy);
-                    ux = fmaf(wb.x, qb, ux); uy = fmaf(wb.y, qb, uy);
-                }
-                u[h] = make_float2(ux, uy);
+                for (int jj = 0; jj < 4; ++jj) qh[4 * i + jj] = t4[jj];
             }
+            wave_lds_fence();
+            float u[16], s[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) { u[c] = 0.f; s[c] = 0.f; }
+#pragma unroll
+            for (int d = 0; d < 16; ++d)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_wk + w_off[i] + d * kC);
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) u[4 * i + jj] = fmaf(w4[jj], qh[d], u[4 * i + jj]);
+                }
 
             // ---- edge loop
-            for (int j = beg; j < end; j += kUnroll) {
-                float2 kk[kUnroll], vv[kUnroll], rr[kUnroll];
+            for (int j = beg; j < end; j += kU) {
 #pragma unroll
-                for (int t = 0; t < kUnroll; ++t) {
-                    const int jj = min(j + t, end - 1);           // clamp, mask below (no per-load branches)
-                    const int src = a.col[jj] + src_off;
-                    const int e = HAS_EID ? a.eid[jj] : jj;
-                    kk[t] = ld2(a.k, src, lane);
-                    vv[t] = ld2(a.v, src, lane);
-                    rr[t] = ld2(a.rhat, e, lane);
-                }
-                float sim[kUnroll];
+                for (int t = 0; t < kU; ++t) *reinterpret_cast<float2 *>(s_stage + t * kC + st_off) = cur.r[t];
+                load_rows(a, src, e, lane, nxt);                                    // rows of iteration j + kU
+                load_indices<HAS_EID>(a, j + 2 * kU, end, src_off, src, e);         // indices of iteration j + 2 kU
+                wave_lds_fence();
+                float r16[kU][16], sim[kU];
                 float smax = -INFINITY;
 #pragma unroll
-                for (int t = 0; t < kUnroll; ++t) {
-                    float p[kH];
+                for (int t = 0; t < kU; ++t) {
 #pragma unroll
-                    for (int h = 0; h < kH; ++h) p[h] = fmaf(u[h].y, rr[t].y, u[h].x * rr[t].x);
-                    // transposed butterfly: 8 per-head partials over 64 lanes -> head (lane >> 3) on every lane
-                    const float t0 = fold32(p[0], p[4]), t1 = fold32(p[1], p[5]);
-                    const float t2 = fold32(p[2], p[6]), t3 = fold32(p[3], p[7]);
-                    const float w0 = fold16(t0, t2), w1 = fold16(t1, t3);
-                    const bool hi = (lane & 8) != 0;
-                    const float keep = hi ? w1 : w0, give = hi ? w0 : w1;
-                    float part = keep + dpp_mov<0x128>(give);      // row_ror:8
-                    part += fmaf(qv.y, kk[t].y, qv.x * kk[t].x);
-                    part = head_sum(part);
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(s_stage + t * kC + r_off[i]);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) r16[t][4 * i + jj] = t4[jj];
+                    }
+                    float p0 = qv.x * cur.k[t].x, p1 = qv.y * cur.k[t].y;
+#pragma unroll
+                    for (int c = 0; c < 16; c += 2) {
+                        p0 = fmaf(u[c], r16[t][c], p0);
+                        p1 = fmaf(u[c + 1], r16[t][c + 1], p1);
+                    }
+                    const float part = head_sum(p0 + p1);
                     sim[t] = (j + t < end) ? part : -INFINITY;
                     smax = fmaxf(smax, sim[t]);
                 }
+                wave_lds_fence();                                  // staging rows are free again
                 const float mn = fmaxf(m, smax);
                 if (!__all(mn == m)) {                             // running max moved for some head: rescale
                     const float alpha = __builtin_amdgcn_exp2f(m - mn);
                     l *= alpha; accv.x *= alpha; accv.y *= alpha;
 #pragma unroll
-                    for (int h = 0; h < kH; ++h) {
-                        const float ah = bcast_lane(alpha, 8 * h);
-                        s[h].x *= ah; s[h].y *= ah;
-                    }
+                    for (int c = 0; c < 16; ++c) s[c] *= alpha;
                     m = mn;
                 }
 #pragma unroll
-                for (int t = 0; t < kUnroll; ++t) {
+                for (int t = 0; t < kU; ++t) {
                     const float pe = __builtin_amdgcn_exp2f(sim[t] - m);
                     l += pe;
-                    accv.x = fmaf(pe, vv[t].x, accv.x);
-                    accv.y = fmaf(pe, vv[t].y, accv.y);
+                    accv.x = fmaf(pe, cur.v[t].x, accv.x);
+                    accv.y = fmaf(pe, cur.v[t].y, accv.y);
 #pragma unroll
-                    for (int h = 0; h < kH; ++h) {
-                        const float ph = bcast_lane(pe, 8 * h);
-                        s[h].x = fmaf(ph, rr[t].x, s[h].x);
-                        s[h].y = fmaf(ph, rr[t].y, s[h].y);
-                    }
+                    for (int c = 0; c < 16; ++c) s[c] = fmaf(pe, r16[t][c], s[c]);
                 }
+                cur = nxt;
             }
 
-            // ---- epilogue: out^h[d] = sum_c wv[16h + d][c] * s^h[c]; lane (d16, quarter) sums 32 channels
+            // ---- epilogue: out^h[d] = sum_c wv[16h + d][c] * s^h[c]: in-lane partial over the slice, then a
+            // reduce-scatter over the 8 lanes of the head that leaves d = 2 sub, 2 sub + 1 on lane sub
+            float part[16];
 #pragma unroll
-            for (int h = 0; h < kH; ++h) {
-                s_vec[wave][lane] = s[h];
-                wave_lds_fence();
-                float acc = 0.f;
-                const int o = 16 * h + d16;
+            for (int d = 0; d < 16; ++d) {
+                float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-                for (int jj = 0; jj < 16; ++jj) {
-                    const int slot = 16 * quarter + jj;
-                    const float2 w = s_wv[o][slot ^ d16];
-                    const float2 sv = s_vec[wave][slot];
-                    acc = fmaf(w.x, sv.x, acc);
-                    acc = fmaf(w.y, sv.y, acc);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_wv + w_off[i] + d * kC);
+                    p0 = fmaf(w4[0], s[4 * i], p0);
+                    p1 = fmaf(w4[1], s[4 * i + 1], p1);
+                    p0 = fmaf(w4[2], s[4 * i + 2], p0);
+                    p1 = fmaf(w4[3], s[4 * i + 3], p1);
                 }
-                acc += __shfl_xor(acc, 16);
-                acc += __shfl_xor(acc, 32);
-                if (quarter == 0) s_out[wave][o] = acc;
-                wave_lds_fence();
+                part[d] = p0 + p1;
+            }
+            float r1[8], r2[4];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {       // partner 7 - sub (opposite bit 2): keep d with bit 3 == own bit 2
+                const float keep = b2 ? part[d + 8] : part[d], give = b2 ? part[d] : part[d + 8];
+                r1[d] = keep + dpp_mov<kDppMirror8>(give);
+            }
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {       // partner sub ^ 2: keep d with bit 2 == own bit 1
+                const float keep = b1 ? r1[d + 4] : r1[d], give = b1 ? r1[d] : r1[d + 4];
+                r2[d] = keep + dpp_mov<kDppXor2>(give);
+            }
+            {                                   // partner sub ^ 1: keep d with bit 1 == own bit 0
+                const float k0 = b0 ? r2[2] : r2[0], g0 = b0 ? r2[0] : r2[2];
+                const float k1 = b0 ? r2[3] : r2[1], g1 = b0 ? r2[1] : r2[3];
+                proj.x = k0 + dpp_mov<kDppXor1>(g0);
+                proj.y = k1 + dpp_mov<kDppXor1>(g1);
             }
         }
-        float2 proj = make_float2(0.f, 0.f);
-        if (end > beg) proj = *reinterpret_cast<const float2 *>(&s_out[wave][2 * lane]);
         const float inv = 1.0f / (l + 1e-16f);        // PyG softmax denominator
         const float asum = l * inv;                   // A_i^h: 1 for non-empty segments, 0 for empty ones
         float2 o2;
         o2.x = fmaf(inv, proj.x + accv.x, asum * bias.x);
         o2.y = fmaf(inv, proj.y + accv.y, asum * bias.y);
         *reinterpret_cast<float2 *>(a.out + node * kC + 2 * lane) = o2;
-        wave_lds_fence();
     }
 }
 
