@@ -181,7 +181,8 @@ int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const f
 int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);
 
 /* Optional per-launch timing of the hand-written kernels with hipEvents on the launch stream (bench.py roofline
- * leg).  qcn_prof_enable(1) starts recording; qcn_prof_collect(kind, ...) synchronises the recorded events of one
+ * leg).  qcn_prof_enable(mask) records the kernel families whose bit (1 << kind) is set
+ * (negative: all, 0: off; each recorded launch costs two event records on the stream, so time only what is reported); qcn_prof_collect(kind, ...) synchronises the recorded events of one
  * kernel family (0 = qcn_attn_fwd_f32, 1 = qcn_attn_fused_f32, ...; -1 = all) and returns the number of launches,
  * the summed kernel milliseconds and the summed algorithmic units (bytes for the HBM-bound kernels:
  * SURVEY.md §8(d) 2064*E + 1024*n_dst materialised, 1552*E + 1024*n_dst fused, 1040*E + 1024*n_dst without

@@ -7,14 +7,14 @@ namespace {
 struct ProfRecord { hipEvent_t start, stop; double units; int kind; };
 std::mutex g_prof_mutex;
 std::vector<ProfRecord *> g_prof_log;
-bool g_prof_on = false;
+unsigned g_prof_mask = 0;   // bit k: record launches of kernel family k
 }  // namespace
 
 void *qcn_prof_begin(int kind, double alg_units, hipStream_t stream)
 {
     {
         std::lock_guard<std::mutex> lock(g_prof_mutex);
-        if (!g_prof_on) return nullptr;
+        if (!((g_prof_mask >> kind) & 1u)) return nullptr;
     }
     ProfRecord *rec = new ProfRecord();
     rec->units = alg_units;
@@ -37,7 +37,7 @@ void qcn_prof_end(void *token, hipStream_t stream)
 extern "C" int qcn_prof_enable(int on)
 {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
-    g_prof_on = on != 0;
+    g_prof_mask = on < 0 ? ~0u : (unsigned)on;
     return QCN_OK;
 }
 

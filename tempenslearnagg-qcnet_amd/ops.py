@@ -305,8 +305,10 @@ def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Te
 # ------------------------------------------------------------------------------------------------
 # profiling hooks for bench.py
 # ------------------------------------------------------------------------------------------------
-def prof_enable(on: bool) -> None:
-    _lib.check(_lib.lib().qcn_prof_enable(int(bool(on))), 'qcn_prof_enable')
+def prof_enable(on, kinds=None) -> None:
+    """Record hipEvent timings of the given kernel families (``kinds``: iterable of PROF_*; default all)."""
+    mask = 0 if not on else (-1 if kinds is None else sum(1 << int(k) for k in kinds))
+    _lib.check(_lib.lib().qcn_prof_enable(mask), 'qcn_prof_enable')
 
 
 PROF_ATTN, PROF_ATTN_FUSED, PROF_FOURIER, PROF_GEMM = 0, 1, 2, 3
