@@ -123,13 +123,30 @@ int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const flo
                        int64_t num_edges, int rep, int layout, int64_t col_shift, const int64_t *group_host,
                        float *out, void *stream);
 
-/* Chain-packed 128x128 matrix — the weight layout of the three MFMA chain kernels below (csrc/chain_tile.hip.h).
- * For W = nn.Linear(128,128).weight ([out][in]) the 16384 floats are
- *   P[s][lane][t] = W[32 t + (lane & 31)][kin(s, lane >> 5)],   s = 0..63, lane = 0..63, t = 0..3,
- * where kin(s, h) = 32 (s >> 4) + (s & 3) + 8 ((s & 15) >> 2) + 4 h is the input feature that k-step s of the
- * v_mfma_f32_32x32x2_f32 chain takes from lane half h (the register layout of a row vector).  The first layer of a
- * FourierEmbedding MLP uses kin(s, h) = 32 h + s for s < 32 (cosines) and 64 + 32 h + (s - 32) otherwise (sines).
- * Host packer: ops.pack_chain_matrix. */
+/* Arithmetic of the three MFMA chain kernels below (qcn_fourier_embed_f32, qcn_ln_linear_f32, qcn_attn_post_f32).
+ *   QCN_MATMUL_EXACT_F32: v_mfma_f32_32x32x2_f32, exact fp32 fma chains.
+ *   QCN_MATMUL_SPLIT_F16 (default): every fp32 operand carried as hi + lo of two f16 numbers (22 significant bits)
+ *     after an exact power-of-two scaling of each activation row / weight matrix to [2^14, 2^15); products
+ *     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation.  Results agree with the exact mode to a few
+ *     fp32 ulps (operand error <= max(2^-22 |x|, 2^-29 max|x|)); finite for |x| < 2^64.
+ * The mode is process-global, read at launch; weight packs are mode specific (pass the pack made for the mode in force:
+ * ops.pack_chain_matrix consults qcn_get_matmul_mode).  No counterpart in the reference (its matmuls are torch fp32). */
+#define QCN_MATMUL_EXACT_F32 0
+#define QCN_MATMUL_SPLIT_F16 1
+int qcn_set_matmul_mode(int mode);
+int qcn_get_matmul_mode(void);
+
+/* Chain-packed 128x128 matrix — the weight layout of the three MFMA chain kernels (csrc/chain_tile.hip.h): 16384 floats
+ * plus a {scale, 1 / scale} pair that travels in the scale table of the pack.  For W = nn.Linear(128,128).weight
+ * ([out][in]), with kin(s, h) = 32 (s >> 4) + (s & 3) + 8 ((s & 15) >> 2) + 4 h the input feature that position s of
+ * lane half h holds in the register layout of a row vector:
+ *   exact: P[s][lane][t] = W[32 t + (lane & 31)][kin(s, lane >> 5)],  s = 0..63, lane = 0..63, t = 0..3 (fp32);
+ *          scale pair {1, 1}.
+ *   split: W' = W * 2^(15 - e), 2^(e-1) <= max|W| < 2^e; hi = f16(W'), lo = f16(W' - hi);
+ *          P[j][t][p][lane][i] = plane_p(W'[32 t + (lane & 31)][kin(8 j + i, lane >> 5)]),  j = 0..7, p = 0 (hi), 1 (lo),
+ *          i = 0..7 (f16, 32768 of them); scale pair {2^(15 - e), 2^(e - 15)}.
+ * The first layer of a FourierEmbedding MLP uses kin(s, h) = 32 h + s for s < 32 (cosines) and 64 + 32 h + (s - 32)
+ * otherwise (sines).  Host packer: ops.pack_chain_matrix. */
 
 /* A4 — the whole FourierEmbedding.forward (layers/fourier_embedding.py:49-67) in one launch:
  *   x [n_rows, input_dim] (input_dim 0..4; NULL for 0), extra [ceil(n_rows / extra_div), 128] or NULL = the summed
@@ -141,7 +158,8 @@ int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const flo
  *     [mlps.0.0.weight[:, :128] (cos | sin order above), mlps.0.3.weight, mlps.1.0.weight[:, :128], ..., to_out.2.weight]
  *   then per input dim i
  *     [freqs.weight[i] (64) | mlps.i.0.weight[:, 128] | mlps.i.0.bias | mlps.i.1.weight | mlps.i.1.bias | mlps.i.3.bias]
- *   followed by [to_out.0.weight | to_out.0.bias | to_out.2.bias].
+ *   followed by [to_out.0.weight | to_out.0.bias | to_out.2.bias], then the scale table: 32 floats, {scale, 1 / scale}
+ *   per matrix in the order above.
  *   hidden_dim = 128, num_freq_bands = 64 only. */
 size_t qcn_fourier_pack_floats(int input_dim);
 int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
@@ -150,7 +168,7 @@ int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int
 /* A2 node side (K5/K6 of SURVEY.md §2b fused) — xn = LayerNorm(x) (skipped when ln_weight == NULL);
  * y_j = W_j xn + b_j for j < n_out <= 4 (the to_q / to_k / to_v / to_s projections of one AttentionLayer call,
  * layers/attention_layer.py:74-79,115-117,108).  x, y_j, xn_out: [n_rows,128]; wt: n_out chain-packed matrices
- * (16384 floats each); bias: [n_out,128] or NULL; xn_out may be NULL. */
+ * (16384 floats each) followed by their n_out {scale, 1 / scale} pairs; bias: [n_out,128] or NULL; xn_out may be NULL. */
 int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
                       const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
                       float *y3, float *xn_out, void *stream);
@@ -163,7 +181,7 @@ int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, co
  *   [to_g.weight[:, :128], to_g.weight[:, 128:], to_out.weight, then for hb = 0..3:
  *    ff_mlp.0.weight[128hb:128hb+128, :], ff_mlp.3.weight[:, 128hb:128hb+128]]
  * followed by [to_g.bias, to_out.bias, attn_postnorm.{weight,bias}, ff_prenorm.{weight,bias}, ff_mlp.0.bias (512),
- *   ff_mlp.3.bias, ff_postnorm.{weight,bias}].  All tensors [n_rows,128] fp32; out must not alias an input (it parks
+ *   ff_mlp.3.bias, ff_postnorm.{weight,bias}], then the scale table (32 floats, {scale, 1 / scale} per matrix).  All tensors [n_rows,128] fp32; out must not alias an input (it parks
  * x1 between the two residuals). */
 size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,

@@ -64,6 +64,18 @@ extern "C" int qcn_prof_collect(int kind, int64_t *launches_host, double *millis
     return QCN_OK;
 }
 
+namespace { int g_matmul_mode = QCN_MATMUL_SPLIT_F16; }
+int qcn_matmul_mode() { return g_matmul_mode; }
+
+extern "C" int qcn_set_matmul_mode(int mode)
+{
+    if (mode != QCN_MATMUL_EXACT_F32 && mode != QCN_MATMUL_SPLIT_F16) return QCN_ERR_INVALID_ARGUMENT;
+    g_matmul_mode = mode;
+    return QCN_OK;
+}
+
+extern "C" int qcn_get_matmul_mode(void) { return g_matmul_mode; }
+
 extern "C" int qcn_version(void) { return 100; }
 
 extern "C" const char *qcn_status_string(int status)

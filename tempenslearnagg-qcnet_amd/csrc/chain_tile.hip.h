@@ -2,7 +2,15 @@
 // whose work is a CHAIN of 128x128 linear layers with per-row epilogues between them: FourierEmbedding (fourier.hip)
 // and the AttentionLayer node-side blocks (nodeops.hip).
 //
-// Every GEMM is computed transposed, Y^T = W X^T, with v_mfma_f32_32x32x2_f32 (exact fp32 fma chains):
+// Every GEMM is computed transposed, Y^T = W X^T, on the matrix cores, in one of two arithmetic modes (qcn_set_matmul_mode):
+//   exact : v_mfma_f32_32x32x2_f32 — exact fp32 fma chains (bitwise an fmaf loop), 64 cycles per 32x32x2 tile step;
+//   split : every fp32 operand is carried as the unevaluated sum hi + lo of two f16 numbers (22 significant bits) after
+//           an exact power-of-two scaling that puts the largest |element| of the row (resp. of the weight matrix) into
+//           [2^14, 2^15), and the product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+//           (the dropped lo*lo term is below 2^-22 of the product): three 32-cycle MFMAs per 16 k instead of eight
+//           64-cycle ones.  Element-wise operand error <= max(2^-22 |x|, 2^-29 max|x|) — the result is within a few
+//           fp32 ulps of the exact mode (tests/test_gpu_attention.py::test_split_matmul_error), at ~3x the rate.
+// In both modes:
 //   * the WEIGHTS are the MFMA A operand (M = output features, four 32-feature tiles),
 //   * the wave's 32 rows are the N dimension: lane (n = lane & 31, h = lane >> 5) only ever holds data of row n.
 // A row vector lives in 64 registers, f32x16 v[4]:  v[t][r] = feature  32 t + (r & 3) + 8 (r >> 2) + 4 h  of row n.
@@ -59,38 +67,119 @@ __device__ __forceinline__ void stage_matrix(const float *__restrict__ packed, f
     }
 }
 
-// acc (+)= W in  for the matrix staged in `w` (LDS): 64 k-steps, 256 MFMAs, fully unrolled (register indices static).
-// The weight fragment of k-step s + kPrefetch is requested before the MFMAs of k-step s are issued, so the LDS
-// latency never sits between a wave's MFMAs (measured: 117 -> 130 TF/s on an 11-GEMM chain, scripts/dbg/chain_bench).
-constexpr int kPrefetch = 1;
-// `next` != nullptr: the LDS-DMA pieces of the NEXT matrix (into `next_dst`, the other buffer) are issued between the
-// k-steps, one every 64 / pieces steps, instead of in one burst after the barrier: a piece costs its wave ~60-180
-// issue cycles, which hide behind an MFMA already in the pipe but add up when eight are issued back to back.
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+
+// MFMA B operand of one row vector.  exact: the 64 fp32 registers themselves.  split: 2 x 32 registers of packed f16
+// (hi / lo planes) + the row's power-of-two scale and its inverse.
+template <bool SPLIT> struct Operand;
+template <> struct Operand<false> { f32x16 v[4]; };
+template <> struct Operand<true> { half8 hi[8], lo[8]; float sc, usc; };
+
+__device__ __forceinline__ void make_operand(Operand<false> &o, const f32x16 (&in)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o.v[t] = in[t];
+}
+
+__device__ __forceinline__ void make_operand(Operand<true> &o, const f32x16 (&in)[4])
+{
+    float mx[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) mx[t] = fmaxf(mx[t], fabsf(in[t][r]));
+    float m = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+    m = fmaxf(m, xhalf(m));
+    // m = f * 2^(eb - 126), f in [1/2, 1): scale by 2^(15 - (eb - 126)) so that the row maximum lands in [2^14, 2^15).
+    // eb is clamped to [64, 190]: rows below 2^-62 keep a fixed scale, rows of 2^65 and above overflow f16 to inf.
+    int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+    eb = eb < 64 ? 64 : (eb > 190 ? 190 : eb);
+    o.sc = __builtin_bit_cast(float, (268 - eb) << 23);
+    o.usc = __builtin_bit_cast(float, (eb - 14) << 23);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = 8 * (j & 1) + 2 * p;
+            const float x0 = in[j >> 1][r] * o.sc, x1 = in[j >> 1][r + 1] * o.sc;
+            const half2v hh = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+            const float r0 = x0 - (float)hh[0], r1 = x1 - (float)hh[1];      // exact in fp32
+            const half2v ll = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+            o.hi[j][2 * p] = hh[0]; o.hi[j][2 * p + 1] = hh[1];
+            o.lo[j][2 * p] = ll[0]; o.lo[j][2 * p + 1] = ll[1];
+        }
+}
+
 template <int WAVES>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const f32x16 (&in)[4], const f32x4 *w, int lane,
-                                     const float *__restrict__ next = nullptr, f32x4 *next_dst = nullptr, int wave = 0)
+__device__ __forceinline__ void stage_piece(const float *__restrict__ next, f32x4 *next_dst, int wave, int lane, int i)
 {
     constexpr int kPieces = (kMatVec4 / 64) / WAVES;   // 1 KiB pieces per wave
+    const int piece = wave * kPieces + i;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(next + ((size_t)piece * 64 + lane) * 4),
+                                     (__attribute__((address_space(3))) void *)(next_dst + piece * 64), 16, 0, 0);
+}
+
+// acc += W in  for the matrix staged in `w` (LDS), fully unrolled (register indices static).  `mscale` = {sw, uw}: the
+// matrix' power-of-two scale and its inverse (split mode; ignored in exact mode).
+// `next` != nullptr: the LDS-DMA pieces of the NEXT matrix (into `next_dst`, the other buffer) are issued between the
+// k-steps instead of in one burst after the barrier: a piece costs its wave ~60-180 issue cycles, which hide behind an
+// MFMA already in the pipe but add up when eight are issued back to back.
+// exact: 64 k-steps x 4 tiles; the weight fragment of k-step s + 1 is requested before the MFMAs of k-step s are all
+// issued, so the LDS latency never sits between a wave's MFMAs.
+template <int WAVES>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<false> &in, const f32x4 *w,
+                                     const float *__restrict__, int lane, const float *__restrict__ next = nullptr,
+                                     f32x4 *next_dst = nullptr, int wave = 0)
+{
+    constexpr int kPieces = (kMatVec4 / 64) / WAVES;
     constexpr int kEvery = 64 / kPieces;
-    f32x4 ring[kPrefetch];
-#pragma unroll
-    for (int i = 0; i < kPrefetch; ++i) ring[i] = w[i * 64 + lane];
+    f32x4 nxt = w[lane];
 #pragma unroll
     for (int s = 0; s < 64; ++s) {
-        const f32x4 a = ring[s % kPrefetch];
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], in[s >> 4][s & 15], acc[0], 0, 0, 0);
-        if (s + kPrefetch < 64) ring[s % kPrefetch] = w[(s + kPrefetch) * 64 + lane];
-        const float b = in[s >> 4][s & 15];
+        const f32x4 a = nxt;
+        const float b = in.v[s >> 4][s & 15];
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b, acc[0], 0, 0, 0);
+        if (s + 1 < 64) nxt = w[(s + 1) * 64 + lane];
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b, acc[1], 0, 0, 0);
-        if (s % kEvery == 0 && next != nullptr) {
-            const int piece = wave * kPieces + s / kEvery;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(next + ((size_t)piece * 64 + lane) * 4),
-                                             (__attribute__((address_space(3))) void *)(next_dst + piece * 64), 16, 0, 0);
-        }
+        if (s % kEvery == 0 && next != nullptr) stage_piece<WAVES>(next, next_dst, wave, lane, s / kEvery);
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b, acc[2], 0, 0, 0);
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b, acc[3], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the request-ahead order: hipcc otherwise sinks the reads to their use
     }
+}
+
+// split: 8 k16-steps x 4 tiles x (hi*hi + hi*lo + lo*hi).  LDS image of a matrix: [k16-step j][tile t][plane p][lane]
+// 16-byte fragments (8 f16: out = 32 t + (lane & 31), k = the 8 features of registers 8 (j & 1) .. + 7 of v[j >> 1]).
+// The accumulators are moved to the operands' scale and back by two exact power-of-two multiplies.
+template <int WAVES>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<true> &in, const f32x4 *w,
+                                     const float *__restrict__ mscale, int lane, const float *__restrict__ next = nullptr,
+                                     f32x4 *next_dst = nullptr, int wave = 0)
+{
+    constexpr int kPieces = (kMatVec4 / 64) / WAVES;
+    constexpr int kEvery = 32 / kPieces > 0 ? 32 / kPieces : 1;
+    constexpr int kPerSlot = kPieces > 32 ? kPieces / 32 : 1;
+    const float S = in.sc * mscale[0], U = in.usc * mscale[1];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] *= S;
+    f32x4 nh = w[lane], nl = w[64 + lane];
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {            // g = 4 j + t
+        const int j = g >> 2, t = g & 3;
+        const half8 ah = __builtin_bit_cast(half8, nh), al = __builtin_bit_cast(half8, nl);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], acc[t], 0, 0, 0);
+        if (g + 1 < 32) { nh = w[(2 * (g + 1)) * 64 + lane]; nl = w[(2 * (g + 1) + 1) * 64 + lane]; }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.lo[j], acc[t], 0, 0, 0);
+        if (g % kEvery == 0 && next != nullptr) {
+#pragma unroll
+            for (int i = 0; i < kPerSlot; ++i) stage_piece<WAVES>(next, next_dst, wave, lane, (g / kEvery) * kPerSlot + i);
+        }
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in.hi[j], acc[t], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] *= U;
 }
 
 // per-feature vector (bias, LayerNorm affine, ...) in register layout: 16 broadcast float4 loads
@@ -177,8 +266,9 @@ __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restri
 
 // rows-per-block choice: WAVES waves x 32 rows.  A block always stages whole matrices, so fewer waves per block only
 // pays when the launch would otherwise leave CUs idle or the last round of blocks mostly empty.
-__host__ inline int pick_waves(int64_t n_rows, int n_cus = 256)
+__host__ inline int pick_waves(int64_t n_rows, bool split, int n_cus = 256)
 {
+    (void)split;
     int best = 8;
     double best_cost = 1e300;
     for (int w = 8; w >= 2; w >>= 1) {
@@ -189,5 +279,19 @@ __host__ inline int pick_waves(int64_t n_rows, int n_cus = 256)
     }
     return best;
 }
+
+// launch one of the <SPLIT, WAVES> instantiations through a caller-defined QCN_LAUNCH(S, W)
+#define QCN_CHAIN_DISPATCH(split, waves)                         \
+    do {                                                         \
+        if (split) {                                             \
+            if ((waves) == 8) QCN_LAUNCH(true, 8);               \
+            else if ((waves) == 4) QCN_LAUNCH(true, 4);          \
+            else QCN_LAUNCH(true, 2);                            \
+        } else {                                                 \
+            if ((waves) == 8) QCN_LAUNCH(false, 8);              \
+            else if ((waves) == 4) QCN_LAUNCH(false, 4);         \
+            else QCN_LAUNCH(false, 2);                           \
+        }                                                        \
+    } while (0)
 
 }  // namespace qcn_chain

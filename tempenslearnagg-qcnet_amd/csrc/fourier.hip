@@ -21,11 +21,12 @@ using namespace qcn_chain;
 //   matrices (chain-packed, 16384 each): [W1_0, W2_0, W1_1, W2_1, ..., Wout]
 //   then per input dim: freq[64], w1_last[128], b1, ln_g, ln_b, b2            (kDimVecs floats)
 //   then to_out: ln_g, ln_b, b                                               (3 * 128)
+//   then {scale, 1 / scale} per matrix                                       (32 floats reserved)
 constexpr int kVFreq = 0, kVW1Last = 64, kVB1 = 64 + kC, kVG1 = 64 + 2 * kC, kVBe1 = 64 + 3 * kC, kVB2 = 64 + 4 * kC,
               kDimVecs = 64 + 5 * kC;
-constexpr int kVOutG = 0, kVOutBe = kC, kVOutB = 2 * kC, kOutVecs = 3 * kC;
+constexpr int kVOutG = 0, kVOutBe = kC, kVOutB = 2 * kC, kOutVecs = 3 * kC, kScales = 32;
 
-template <int IN, int WAVES>
+template <int IN, bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__restrict__ x,
                                                              const float *__restrict__ extra, int extra_div,
                                                              const float *__restrict__ pack, float *__restrict__ y,
@@ -42,6 +43,8 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     const float *mats = pack;
     const float *vecs = pack + (size_t)(2 * IN + 1) * kMatFloats;
     const float *out_vec = vecs + IN * kDimVecs;
+    const float *msc = out_vec + kOutVecs;
+    Operand<SPLIT> op;
 
     stage_matrix<WAVES>(mats, buf0, wave, lane);
 
@@ -79,8 +82,9 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc_h[t][4 * q + j] = fmaf(xv, wl[j], b1[j]);
             }
+        make_operand(op, ft);
         sync_for_stage();
-        gemm<WAVES>(acc_h, ft, buf0, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
+        gemm<WAVES>(acc_h, op, buf0, msc + 4 * d, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
         layer_norm<true, true>(acc_h, dv + kVG1, dv + kVBe1, h, eps);
         // ---- y += W2 h + b2
 #pragma unroll
@@ -91,8 +95,9 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc_y[t][4 * q + j] += b2[j];
             }
+        make_operand(op, acc_h);
         sync_for_stage();
-        gemm<WAVES>(acc_y, acc_h, buf1, lane, mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
+        gemm<WAVES>(acc_y, op, buf1, msc + 4 * d + 2, lane, mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
     }
 
     if (extra != nullptr) {   // summed categorical embeddings (:65-66)
@@ -106,8 +111,9 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     layer_norm<true, true>(acc_y, out_vec + kVOutG, out_vec + kVOutBe, h, eps);
     f32x16 acc_o[4];
     load_feature_vec(acc_o, out_vec + kVOutB, h);
+    make_operand(op, acc_y);
     sync_for_stage();
-    gemm<WAVES>(acc_o, acc_y, buf0, lane);
+    gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane);
     if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
     if (valid) store_row(acc_o, y, row, h);
 }
@@ -116,7 +122,7 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 
 extern "C" size_t qcn_fourier_pack_floats(int input_dim)
 {
-    return (size_t)(2 * input_dim + 1) * kMatFloats + (size_t)input_dim * kDimVecs + kOutVecs;
+    return (size_t)(2 * input_dim + 1) * kMatFloats + (size_t)input_dim * kDimVecs + kOutVecs + kScales;
 }
 
 extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
@@ -127,28 +133,32 @@ extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float 
     if (!pack || !y || (input_dim > 0 && !x) || (input_dim == 0 && !extra)) return QCN_ERR_INVALID_ARGUMENT;
     if (extra_div < 1 || extra_div > 0x7fffffff) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const int waves = pick_waves(n_rows);
+    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
+    const int waves = pick_waves(n_rows, split);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC);
     void *token = qcn_prof_begin(QCN_PROF_FOURIER, flops, s);
-#define QCN_LAUNCH_FOURIER(IN, W)                                                                                    \
-    hipLaunchKernelGGL((fourier_kernel<IN, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, n_rows, \
-                       normalize_out)
-#define QCN_LAUNCH_FOURIER_W(IN)                                                                                     \
-    do {                                                                                                             \
-        if (waves == 8) QCN_LAUNCH_FOURIER(IN, 8);                                                                   \
-        else if (waves == 4) QCN_LAUNCH_FOURIER(IN, 4);                                                              \
-        else QCN_LAUNCH_FOURIER(IN, 2);                                                                              \
-    } while (0)
+#define QCN_LAUNCH(S, W)                                                                                           \
+    hipLaunchKernelGGL((fourier_kernel<QCN_IN, S, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, \
+                       n_rows, normalize_out)
     switch (input_dim) {
-    case 0: QCN_LAUNCH_FOURIER_W(0); break;
-    case 1: QCN_LAUNCH_FOURIER_W(1); break;
-    case 2: QCN_LAUNCH_FOURIER_W(2); break;
-    case 3: QCN_LAUNCH_FOURIER_W(3); break;
-    default: QCN_LAUNCH_FOURIER_W(4); break;
+#define QCN_IN 0
+    case 0: QCN_CHAIN_DISPATCH(split, waves); break;
+#undef QCN_IN
+#define QCN_IN 1
+    case 1: QCN_CHAIN_DISPATCH(split, waves); break;
+#undef QCN_IN
+#define QCN_IN 2
+    case 2: QCN_CHAIN_DISPATCH(split, waves); break;
+#undef QCN_IN
+#define QCN_IN 3
+    case 3: QCN_CHAIN_DISPATCH(split, waves); break;
+#undef QCN_IN
+#define QCN_IN 4
+    default: QCN_CHAIN_DISPATCH(split, waves); break;
+#undef QCN_IN
     }
-#undef QCN_LAUNCH_FOURIER_W
-#undef QCN_LAUNCH_FOURIER
+#undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;

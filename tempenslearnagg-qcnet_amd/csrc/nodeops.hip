@@ -18,7 +18,7 @@ namespace {
 
 using namespace qcn_chain;
 
-template <int WAVES>
+template <bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__restrict__ x, int64_t n_rows,
                                                                const float *__restrict__ ln_g,
                                                                const float *__restrict__ ln_b,
@@ -40,14 +40,17 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
     load_row(xv, x, rowc, h);
     if (ln_g != nullptr) layer_norm<true, false>(xv, ln_g, ln_b, h, 1e-5f);
     if (xn_out != nullptr && valid) store_row(xv, xn_out, row, h);
+    const float *mscale = wp + (size_t)n_out * kMatFloats;   // {scale, 1 / scale} per matrix
+    Operand<SPLIT> xo;
+    make_operand(xo, xv);
 #pragma unroll 1
     for (int j = 0; j < n_out; ++j) {
         f32x16 acc[4];
         if (bias != nullptr) load_feature_vec(acc, bias + j * kC, h);
         else fill_zero(acc);
         sync_for_stage();   // matrix j has landed (every wave drained its DMA), buffer (j+1)&1 is no longer read
-        gemm<WAVES>(acc, xv, wlds + (j & 1) * kMatVec4, lane, j + 1 < n_out ? wp + (size_t)(j + 1) * kMatFloats : nullptr,
-                    wlds + ((j + 1) & 1) * kMatVec4, wave);
+        gemm<WAVES>(acc, xo, wlds + (j & 1) * kMatVec4, mscale + 2 * j, lane,
+                    j + 1 < n_out ? wp + (size_t)(j + 1) * kMatFloats : nullptr, wlds + ((j + 1) & 1) * kMatVec4, wave);
         float *y = j == 0 ? y0 : j == 1 ? y1 : j == 2 ? y2 : y3;
         if (valid) store_row(acc, y, row, h);
     }
@@ -55,11 +58,12 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
 
 // pack: 11 chain-packed matrices in consumption order [Wg_agg, Wg_x, Wout, W1_0, W2_0, W1_1, W2_1, W1_2, W2_2, W1_3, W2_3]
 // then plain vectors [bg, bout, lnpost_g, lnpost_b, lnffpre_g, lnffpre_b, b1 (512), b2, lnffpost_g, lnffpost_b]
+// then {scale, 1 / scale} per matrix (32 floats reserved)
 constexpr int kPostMats = 11;
 constexpr int kVBg = 0, kVBout = kC, kVLpG = 2 * kC, kVLpB = 3 * kC, kVLfG = 4 * kC, kVLfB = 5 * kC, kVB1 = 6 * kC,
-              kVB2 = 10 * kC, kVLqG = 11 * kC, kVLqB = 12 * kC, kPostVecs = 13 * kC;
+              kVB2 = 10 * kC, kVLqG = 11 * kC, kVLqB = 12 * kC, kPostVecs = 13 * kC, kPostScales = 32;
 
-template <int WAVES>
+template <bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__restrict__ agg,
                                                                const float *__restrict__ xn,
                                                                const float *__restrict__ s,
@@ -76,20 +80,24 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     const int64_t rowc = valid ? row : n_rows - 1;
     const float *mats = pack;
     const float *vec = pack + (size_t)kPostMats * kMatFloats;
+    const float *msc = vec + kPostVecs;
     const float eps = 1e-5f;
+    Operand<SPLIT> op;
 
     stage_matrix<WAVES>(mats, buf0, wave, lane);
     // ---- gate: g = sigmoid(Wg [agg, xn] + bg)
     f32x16 va[4], acc[4];
     load_row(va, agg, rowc, h);
     load_feature_vec(acc, vec + kVBg, h);
+    make_operand(op, va);
     sync_for_stage();
-    gemm<WAVES>(acc, va, buf0, lane, mats + kMatFloats, buf1, wave);
+    gemm<WAVES>(acc, op, buf0, msc + 0, lane, mats + kMatFloats, buf1, wave);
     {
         f32x16 vx[4];
         load_row(vx, xn, rowc, h);
+        make_operand(op, vx);
         sync_for_stage();
-        gemm<WAVES>(acc, vx, buf1, lane, mats + 2 * kMatFloats, buf0, wave);
+        gemm<WAVES>(acc, op, buf1, msc + 2, lane, mats + 2 * kMatFloats, buf0, wave);
     }
     // ---- u = agg + g * (s - agg)
     {
@@ -105,8 +113,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     }
     // ---- x1 = x + LN_post(Wout u + bout); parked in `out` until the last residual
     load_feature_vec(acc, vec + kVBout, h);
+    make_operand(op, va);
     sync_for_stage();
-    gemm<WAVES>(acc, va, buf0, lane, mats + 3 * kMatFloats, buf1, wave);
+    gemm<WAVES>(acc, op, buf0, msc + 4, lane, mats + 3 * kMatFloats, buf1, wave);
     layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
     f32x16 x1[4];
     load_row(x1, xres, rowc, h);
@@ -115,6 +124,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     if (valid) store_row(x1, out, row, h);
     // ---- feed-forward block, hidden layer in four 128-wide blocks
     layer_norm<true, false>(x1, vec + kVLfG, vec + kVLfB, h, eps);
+    make_operand(op, x1);
     f32x16 acc_o[4];
     load_feature_vec(acc_o, vec + kVB2, h);
 #pragma unroll 1
@@ -122,13 +132,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         const float *w1 = mats + (size_t)(3 + 2 * hb) * kMatFloats;
         load_feature_vec(acc, vec + kVB1 + hb * kC, h);
         sync_for_stage();
-        gemm<WAVES>(acc, x1, buf1, lane, w1 + kMatFloats, buf0, wave);
+        gemm<WAVES>(acc, op, buf1, msc + 2 * (3 + 2 * hb), lane, w1 + kMatFloats, buf0, wave);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
+        Operand<SPLIT> hid;
+        make_operand(hid, acc);
         sync_for_stage();
-        gemm<WAVES>(acc_o, acc, buf0, lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
+        gemm<WAVES>(acc_o, hid, buf0, msc + 2 * (4 + 2 * hb), lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
     }
     layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, h, eps);
     if (valid) {
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
 
 }  // namespace
 
-extern "C" size_t qcn_attn_post_pack_floats(void) { return (size_t)kPostMats * kMatFloats + kPostVecs; }
+extern "C" size_t qcn_attn_post_pack_floats(void) { return (size_t)kPostMats * kMatFloats + kPostVecs + kPostScales; }
 
 extern "C" int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
                                  const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
@@ -152,15 +164,14 @@ extern "C" int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln
     if (!x || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2) || (n_out > 3 && !y3)) return QCN_ERR_INVALID_ARGUMENT;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const int waves = pick_waves(n_rows);
+    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
+    const int waves = pick_waves(n_rows, split);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * n_out * 2.0 * kMatFloats, s);
-#define QCN_LAUNCH(W)                                                                                              \
-    hipLaunchKernelGGL((ln_linear_kernel<W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, ln_weight, ln_bias, wt, bias, \
+#define QCN_LAUNCH(S, W)                                                                                           \
+    hipLaunchKernelGGL((ln_linear_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, ln_weight, ln_bias, wt, bias, \
                        n_out, y0, y1, y2, y3, xn_out)
-    if (waves == 8) QCN_LAUNCH(8);
-    else if (waves == 4) QCN_LAUNCH(4);
-    else QCN_LAUNCH(2);
+    QCN_CHAIN_DISPATCH(split, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
@@ -175,15 +186,14 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
     if (!agg || !xn_dst || !s_proj || !x_res || !pack || !out) return QCN_ERR_INVALID_ARGUMENT;
     if (out == agg || out == xn_dst || out == s_proj || out == x_res) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const int waves = pick_waves(n_rows);
+    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
+    const int waves = pick_waves(n_rows, split);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * kPostMats * 2.0 * kMatFloats, s);
-#define QCN_LAUNCH(W)                                                                                             \
-    hipLaunchKernelGGL((attn_post_kernel<W>), dim3(grid), dim3(64 * W), 0, s, agg, xn_dst, s_proj, x_res, pack, n_rows, \
+#define QCN_LAUNCH(S, W)                                                                                          \
+    hipLaunchKernelGGL((attn_post_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, agg, xn_dst, s_proj, x_res, pack, n_rows, \
                        out)
-    if (waves == 8) QCN_LAUNCH(8);
-    else if (waves == 4) QCN_LAUNCH(4);
-    else QCN_LAUNCH(2);
+    QCN_CHAIN_DISPATCH(split, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);

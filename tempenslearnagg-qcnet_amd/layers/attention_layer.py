@@ -86,29 +86,30 @@ class AttentionLayer(nn.Module):
         ``pre_*``: chain-packed projection stacks for qcn_ln_linear_f32; ``post``: qcn_attn_post_f32 pack;
         ``pos``: (wk, wv, bv) for qcn_attn_fused_f32 with the attn_prenorm_r affine folded in
         (wk = to_k_r.weight * gamma, wv = to_v_r.weight * gamma, bv = to_v_r.weight @ beta + to_v_r.bias)."""
-        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if key == self._pack_key:
             return self._packs
         C = ops.C
         with torch.no_grad():
             zero = torch.zeros(C, device=self.to_q.weight.device)
-            t = lambda lin: ops.pack_chain_matrix(lin.weight)
+            stack = lambda *lins: ops.pack_chain_matrices([lin.weight for lin in lins])
             packs = {}
-            packs['pre_src'] = (torch.stack([t(self.to_k), t(self.to_v)]).contiguous(),
-                                torch.stack([zero, self.to_v.bias]).contiguous())
-            packs['pre_dst'] = (torch.stack([t(self.to_q), t(self.to_s)]).contiguous(),
+            packs['pre_src'] = (stack(self.to_k, self.to_v), torch.stack([zero, self.to_v.bias]).contiguous())
+            packs['pre_dst'] = (stack(self.to_q, self.to_s),
                                 torch.stack([self.to_q.bias, self.to_s.bias]).contiguous())
-            packs['pre_all'] = (torch.stack([t(self.to_q), t(self.to_k), t(self.to_v), t(self.to_s)]).contiguous(),
+            packs['pre_all'] = (stack(self.to_q, self.to_k, self.to_v, self.to_s),
                                 torch.stack([self.to_q.bias, zero, self.to_v.bias, self.to_s.bias]).contiguous())
             mats = [self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_out.weight]
             w1, w2 = self.ff_mlp[0], self.ff_mlp[3]
             for hb in range(4):
                 mats += [w1.weight[hb * C:(hb + 1) * C, :], w2.weight[:, hb * C:(hb + 1) * C]]
-            mats = [ops.pack_chain_matrix(m) for m in mats]
+            mats, scales = ops.pack_chain_set(mats)
+            mats = [mats]
             vecs = [self.to_g.bias, self.to_out.bias, self.attn_postnorm.weight, self.attn_postnorm.bias,
                     self.ff_prenorm.weight, self.ff_prenorm.bias, w1.bias, w2.bias, self.ff_postnorm.weight,
                     self.ff_postnorm.bias]
-            packs['post'] = torch.cat([m.reshape(-1) for m in mats] + [v.reshape(-1) for v in vecs]).float().contiguous()
+            packs['post'] = torch.cat([m.reshape(-1) for m in mats] + [v.reshape(-1).float() for v in vecs]
+                                      + [ops.scale_table(scales)]).contiguous()
             if self.has_pos_emb:
                 gamma, beta = self.attn_prenorm_r.weight, self.attn_prenorm_r.bias
                 packs['pos'] = ((self.to_k_r.weight * gamma.unsqueeze(0)).contiguous(),

@@ -45,9 +45,9 @@ class FourierEmbedding(nn.Module):
     def packed_weights(self) -> torch.Tensor:
         """Parameters in the layout of include/qcnet_hip.h (qcn_fourier_embed_f32), cached per parameter version."""
         params = list(self.parameters())
-        key = tuple((p.data_ptr(), p._version) for p in params)
+        key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self._pack_key:
-            mats, vecs = [], []
+            mats, orders, vecs = [], [], []
             with torch.no_grad():
                 nf = 2 * self.num_freq_bands
                 # k-step s of the first layer takes, from lane half h, cos (s < 32) or sin (s >= 32) of frequency
@@ -57,13 +57,16 @@ class FourierEmbedding(nn.Module):
                 first_layer_order = torch.where(s_idx < 32, 32 * h_idx + s_idx, 64 + 32 * h_idx + (s_idx - 32))
                 for i in range(self.input_dim):
                     lin1, ln, _, lin2 = self.mlps[i]
-                    mats += [ops.pack_chain_matrix(lin1.weight[:, :nf], first_layer_order),
-                             ops.pack_chain_matrix(lin2.weight)]
+                    mats += [lin1.weight[:, :nf], lin2.weight]
+                    orders += [first_layer_order, None]
                     vecs += [self.freqs.weight[i], lin1.weight[:, nf], lin1.bias, ln.weight, ln.bias, lin2.bias]
                 ln, _, lin = self.to_out
-                mats.append(ops.pack_chain_matrix(lin.weight))
+                mats.append(lin.weight)
+                orders.append(None)
                 vecs += [ln.weight, ln.bias, lin.bias]
-                self._pack = torch.cat([p.reshape(-1).float() for p in mats + vecs]).contiguous()
+                packed, scales = ops.pack_chain_set(mats, orders)
+                self._pack = torch.cat([packed.reshape(-1)] + [p.reshape(-1).float() for p in vecs]
+                                       + [ops.scale_table(scales)]).contiguous()
             self._pack_key = key
         return self._pack
 

@@ -91,7 +91,7 @@ class QCNetDecoder(nn.Module):
         """traj_emb parameters in the kernels' layouts (k-major transposes), cached per parameter version."""
         gru = self.traj_emb
         prm = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0, self.traj_emb_h0)
-        key = tuple((p.data_ptr(), p._version) for p in prm)
+        key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in prm)
         if key != getattr(self, '_gru_key', None):
             C = self.hidden_dim
             with torch.no_grad():

@@ -159,27 +159,79 @@ def chain_feature_order(device=None) -> torch.Tensor:
     return (32 * (s >> 4) + (r & 3) + 8 * (r >> 2) + 4 * h).to(device)
 
 
-def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """A ``nn.Linear(128, 128).weight`` ([out, in]) in the order the chain kernels consume it:
-    ``P[s, lane, t] = weight[32 t + (lane & 31), in_index[s, lane >> 5]]`` flattened to 16384 floats.  ``in_index``
-    defaults to :func:`chain_feature_order` (the operand is a register-resident row vector)."""
+MATMUL_EXACT_F32, MATMUL_SPLIT_F16 = 0, 1
+CHAIN_MATRIX_FLOATS = C * C
+
+
+def matmul_mode() -> int:
+    """Arithmetic mode of the MFMA chain kernels (include/qcnet_hip.h: QCN_MATMUL_*)."""
+    return int(_lib.lib().qcn_get_matmul_mode())
+
+
+def set_matmul_mode(mode: int) -> None:
+    _lib.check(_lib.lib().qcn_set_matmul_mode(int(mode)), 'qcn_set_matmul_mode')
+
+
+def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = None,
+                      mode: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """A ``nn.Linear(128, 128).weight`` ([out, in]) in the order the chain kernels consume it, for the matmul mode in
+    force: (16384 floats, {scale, 1 / scale}) — layouts in include/qcnet_hip.h, 'Chain-packed 128x128 matrix'.
+    ``in_index`` [64, 2]: the input column that register position s of lane half h stands for; defaults to
+    :func:`chain_feature_order` (the operand is a register-resident row vector)."""
     if tuple(weight.shape) != (C, C):
         raise ValueError('pack_chain_matrix expects a [128, 128] weight, got %s' % (tuple(weight.shape),))
+    if mode is None:
+        mode = matmul_mode()
     dev = weight.device
     if in_index is None:
         key = str(dev)
         if key not in _CHAIN_INDEX:
             _CHAIN_INDEX[key] = chain_feature_order(dev)
         in_index = _CHAIN_INDEX[key]
+    in_index = in_index.to(dev)
+    w = weight.detach().float()
+    if not bool(torch.isfinite(w).all()):
+        raise ValueError('pack_chain_matrix: weight has non-finite entries')
     out_index = (32 * torch.arange(4, device=dev).view(1, 4) + torch.arange(32, device=dev).view(32, 1))  # [m, t]
-    # P[s, h, m, t]
-    packed = weight.detach().float()[out_index.view(1, 1, 32, 4), in_index.to(dev).view(64, 2, 1, 1)]
-    return packed.reshape(-1).contiguous()
+    if mode == MATMUL_EXACT_F32:
+        packed = w[out_index.view(1, 1, 32, 4), in_index.view(64, 2, 1, 1)]          # P[s, h, m, t]
+        return packed.reshape(-1).contiguous(), torch.ones(2, dtype=torch.float32, device=dev)
+    if mode != MATMUL_SPLIT_F16:
+        raise ValueError('unknown matmul mode %r' % (mode,))
+    _, e = torch.frexp(w.abs().max())                   # max|W| = f * 2^e, f in [1/2, 1)
+    e = int(e) if float(w.abs().max()) > 0 else 0
+    scale = 2.0 ** (15 - e)
+    ws = w * scale                                      # exact (power of two); max|ws| in [2^14, 2^15)
+    hi = ws.half()
+    lo = (ws - hi.float()).half()                       # ws - hi is exact in fp32
+    kin = in_index.view(8, 8, 2).permute(0, 2, 1)       # [j, h, i] = in_index[8 j + i, h]
+    rows = out_index.t().reshape(1, 4, 1, 1, 32, 1)     # [., t, ., ., m, .]
+    cols = kin.reshape(8, 1, 1, 2, 1, 8)                # [j, ., ., h, ., i]
+    planes = torch.stack([hi, lo])                      # [p, out, in]
+    pidx = torch.arange(2, device=dev).view(1, 1, 2, 1, 1, 1)
+    packed = planes[pidx, rows, cols]                   # [j, t, p, h, m, i] f16
+    packed = packed.contiguous().view(-1).view(torch.float32)
+    assert packed.numel() == CHAIN_MATRIX_FLOATS
+    return packed.contiguous(), torch.tensor([scale, 1.0 / scale], dtype=torch.float32, device=dev)
 
 
-def pack_chain_matrices(weights) -> torch.Tensor:
-    """Stack of chain-packed matrices, [len(weights), 16384]."""
-    return torch.stack([pack_chain_matrix(w) for w in weights]).contiguous()
+def pack_chain_set(weights, in_indices=None, mode: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """([n, 16384] chain-packed matrices, [n, 2] scale pairs) for a list of weights."""
+    in_indices = in_indices or [None] * len(weights)
+    pairs = [pack_chain_matrix(w, ix, mode) for w, ix in zip(weights, in_indices)]
+    return torch.stack([p[0] for p in pairs]).contiguous(), torch.stack([p[1] for p in pairs]).contiguous()
+
+
+def pack_chain_matrices(weights, mode: Optional[int] = None) -> torch.Tensor:
+    """The ``wt`` argument of qcn_ln_linear_f32: n chain-packed matrices followed by their n scale pairs, flat."""
+    mats, scales = pack_chain_set(weights, mode=mode)
+    return torch.cat([mats.reshape(-1), scales.reshape(-1)]).contiguous()
+
+
+def scale_table(scales: torch.Tensor, size: int = 32) -> torch.Tensor:
+    """Scale pairs padded to the fixed-size table at the end of the Fourier / attn_post packs."""
+    flat = scales.reshape(-1)
+    return torch.cat([flat, flat.new_ones(size - flat.numel())])
 
 
 def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor, extra: Optional[torch.Tensor] = None,
@@ -207,12 +259,13 @@ def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor,
 def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], wt: torch.Tensor,
               bias: Optional[torch.Tensor], want_xn: bool = False):
     """qcn_ln_linear_f32: ([y_0 .. y_{n_out-1}], xn or None) with y_j = W_j LayerNorm(x) + b_j; ``wt`` is the stack
-    of chain-packed weights [n_out, 16384] (:func:`pack_chain_matrices`), ``bias`` [n_out, 128] or None."""
+    of chain-packed weights and their scale pairs, n_out * (16384 + 2) floats (:func:`pack_chain_matrices`, made for
+    the matmul mode in force), ``bias`` [n_out, 128] or None."""
     dev = x.device
     n = x.size(0)
-    n_out = wt.size(0)
+    n_out = wt.numel() // (C * C + 2)
     _require(x, 'x', torch.float32, dev, (n, C))
-    _require(wt, 'wt', torch.float32, dev, (n_out, C * C))
+    _require(wt, 'wt', torch.float32, dev, (n_out * (C * C + 2),))
     if not 1 <= n_out <= 4:
         raise ValueError('n_out must be 1..4')
     if bias is not None:
@@ -245,7 +298,7 @@ def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_r
 def gru_last_hidden(x_seq: torch.Tensor, n_steps: int, wih_t: torch.Tensor, b_ih: torch.Tensor, whh_t: torch.Tensor,
                     b_hh: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
     """Final hidden state of a 1-layer GRU(128, 128) over ``n_steps`` steps.  ``x_seq`` [n_seq * n_steps, 128] with
-    row = seq * n_steps + t; ``wih_t`` [3, 16384] chain-packed per gate (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` [128, 384];
+    row = seq * n_steps + t; ``wih_t`` = pack_chain_matrices of the three gate matrices (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` [128, 384];
     ``b_hh`` [384]; ``h0`` [128].  Input half: one qcn_ln_linear_f32 launch; recurrence: one qcn_gru_f32 launch."""
     dev = x_seq.device
     _require(x_seq, 'x_seq', torch.float32, dev, (None, C))

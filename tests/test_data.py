@@ -64,7 +64,9 @@ def test_pack_chain_matrix_is_a_permutation_that_keeps_the_linear_map():
     x = torch.randn(128)
     order = ops.chain_feature_order()
     assert sorted(order.reshape(-1).tolist()) == list(range(128))
-    p = ops.pack_chain_matrix(w).view(64, 2, 32, 4)
+    p, sc = ops.pack_chain_matrix(w, mode=ops.MATMUL_EXACT_F32)
+    assert sc.tolist() == [1.0, 1.0]
+    p = p.view(64, 2, 32, 4)
     y = torch.einsum('shmt,sh->mt', p.double(), x[order].double())          # [m, t] -> out feature 32 t + m
     ref = (w.double() @ x.double()).view(4, 32).t()
     assert torch.allclose(y, ref, atol=1e-12)
@@ -73,6 +75,14 @@ def test_pack_chain_matrix_is_a_permutation_that_keeps_the_linear_map():
     h_idx = torch.arange(2).unsqueeze(0)
     first = torch.where(s_idx < 32, 32 * h_idx + s_idx, 64 + 32 * h_idx + (s_idx - 32))
     assert sorted(first.reshape(-1).tolist()) == list(range(128))
-    p1 = ops.pack_chain_matrix(w, first).view(64, 2, 32, 4)
+    p1 = ops.pack_chain_matrix(w, first, mode=ops.MATMUL_EXACT_F32)[0].view(64, 2, 32, 4)
     y1 = torch.einsum('shmt,sh->mt', p1.double(), x[first].double())
     assert torch.allclose(y1, ref, atol=1e-12)
+    # split mode: hi + lo planes of the scaled weight reproduce it to 2^-22, in the [k16-step, tile, plane, lane, i] order
+    ps, sc = ops.pack_chain_matrix(w, mode=ops.MATMUL_SPLIT_F16)
+    planes = ps.view(torch.float16).view(8, 4, 2, 2, 32, 8).double()                 # [j, t, p, h, m, i]
+    wsum = (planes[:, :, 0] + planes[:, :, 1]) * float(sc[1])                        # [j, t, h, m, i]
+    assert float(sc[0]) * float(sc[1]) == 1.0 and 2 ** 14 <= float(w.abs().max()) * float(sc[0]) < 2 ** 15
+    xin = x[order].double().view(8, 8, 2).permute(0, 2, 1)                           # [j, h, i]
+    ys = torch.einsum('jthmi,jhi->mt', wsum, xin)
+    assert torch.allclose(ys, ref, rtol=0, atol=float(w.abs().max()) * float(x.abs().sum()) * 2.0 ** -21)

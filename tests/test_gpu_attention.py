@@ -213,3 +213,50 @@ def test_gru_kernel_matches_torch_gru():
                               gru.weight_hh_l0.detach().t().contiguous().to(DEV), gru.bias_hh_l0.detach().to(DEV),
                               h0.to(DEV))
     assert rel_err(got, want) < 1e-5
+
+
+@pytest.fixture
+def restore_matmul_mode():
+    mode = ops.matmul_mode()
+    yield
+    ops.set_matmul_mode(mode)
+
+
+@pytest.mark.gpu
+def test_split_matmul_error(restore_matmul_mode):
+    """The split-f16 matmul mode (include/qcnet_hip.h: QCN_MATMUL_SPLIT_F16) against fp64, next to the exact fp32 MFMA
+    mode on the same inputs.  Error is measured per output against its own scale sum_k |x_k| |w_k| (the backward-error
+    scale of a dot product); the bar is 2^-19 for both modes — a few fp32 ulps, two orders below the 1e-4 parity budget
+    (measured: exact 1.4e-6 — 128 sequential fp32 roundings —, split 8.7e-7).
+    Rows span 35 decades of magnitude (the per-row power-of-two scaling), one row is zero, the four matrices differ in
+    magnitude by 10^6 (the per-matrix scaling)."""
+    torch.manual_seed(11)
+    n = 3000
+    x = torch.randn(n, 128, device=DEV) * (10.0 ** torch.empty(n, 1, device=DEV).uniform_(-20, 15))
+    x[7] = 0.0
+    x[8, 3:] = 0.0                                  # a single non-zero element
+    ws = [torch.randn(128, 128, device=DEV) * s for s in (1e-3, 0.05, 1.0, 300.0)]
+    bias = torch.randn(4, 128, device=DEV)
+    errs = {}
+    for mode in (ops.MATMUL_EXACT_F32, ops.MATMUL_SPLIT_F16):
+        ops.set_matmul_mode(mode)
+        assert ops.matmul_mode() == mode
+        ys, _ = ops.ln_linear(x, None, None, ops.pack_chain_matrices(ws), bias)
+        worst = 0.0
+        for j, w in enumerate(ws):
+            ref = x.double() @ w.double().t() + bias[j].double()
+            scale = x.double().abs() @ w.double().abs().t() + bias[j].double().abs()
+            worst = max(worst, float(((ys[j].double() - ref).abs() / scale.clamp_min(1e-300)).max()))
+            assert torch.isfinite(ys[j]).all()
+        errs[mode] = worst
+    print('matmul backward error: exact %.3g  split %.3g' % (errs[ops.MATMUL_EXACT_F32], errs[ops.MATMUL_SPLIT_F16]))
+    assert errs[ops.MATMUL_EXACT_F32] < 2.0 ** -19
+    assert errs[ops.MATMUL_SPLIT_F16] < 2.0 ** -19
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('mode', [ops.MATMUL_EXACT_F32, ops.MATMUL_SPLIT_F16])
+def test_attention_layer_vs_oracle_in_both_matmul_modes(mode, restore_matmul_mode):
+    ops.set_matmul_mode(mode)
+    test_attention_layer_vs_oracle(True, True)
+    test_attention_layer_vs_oracle(False, True)
