@@ -113,15 +113,16 @@ int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, const float
  * rowptr entries are offsets into col / eid and need not start at 0: a window of consecutive rows of a larger graph is
  * passed as a pointer into that graph's rowptr (the sliding frames of predictors/temp_ens_learn_agg.py:197 are such
  * windows of one absolute-time graph); col_shift is subtracted from every col entry to re-base source ids.
- * group_host (HOST pointer to 4 int64, or NULL): all frames in one launch.  {group_rows, group_row_shift,
- * group_col_shift, group_src_stride}: destination idx belongs to frame g = idx / group_rows and uses CSR row
- * idx % group_rows + g * group_row_shift; its sources are rows col - col_shift - g * group_col_shift + g * group_src_stride
- * of k / v (n_rows = rows of the absolute graph, layout 0, rep 1, n_dst = frames * group_rows). */
+ * row_index / src_offset (device int32 [n_dst], each may be NULL; layout 0, rep 1 only): destination idx uses CSR row
+ * row_index[idx] (default idx) of the n_rows-row graph and reads source rows col - col_shift + src_offset[idx] of k / v.
+ * Several destination sets over one CSR without copying it: the sliding frames of an absolute-time relation, the
+ * per-frame special steps of the streaming encoder.  The caller guarantees 0 <= row_index[idx] < n_rows and
+ * 0 <= source row < n_src (CSRGraph.validate checks both on request). */
 int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const float *rhat,
                        const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *wk,
                        const float *wv, const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows,
-                       int64_t num_edges, int rep, int layout, int64_t col_shift, const int64_t *group_host,
-                       float *out, void *stream);
+                       int64_t num_edges, int rep, int layout, int64_t col_shift, const int32_t *row_index,
+                       const int32_t *src_offset, float *out, void *stream);
 
 /* Arithmetic of the three MFMA chain kernels below (qcn_fourier_embed_f32, qcn_ln_linear_f32, qcn_attn_post_f32).
  *   QCN_MATMUL_EXACT_F32: v_mfma_f32_32x32x2_f32, exact fp32 fma chains.

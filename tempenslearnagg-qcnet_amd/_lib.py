@@ -40,7 +40,7 @@ def _declare(lib) -> None:
     lib.qcn_attn_fwd_f32.argtypes = [P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, P, P]
     lib.qcn_attn_fused_f32.restype = c_int
     lib.qcn_attn_fused_f32.argtypes = [P, P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
-                                       c_int64, P, P, P]
+                                       c_int64, P, P, P, P]
     lib.qcn_fourier_pack_floats.restype = c_size_t
     lib.qcn_fourier_pack_floats.argtypes = [c_int]
     lib.qcn_fourier_embed_f32.restype = c_int

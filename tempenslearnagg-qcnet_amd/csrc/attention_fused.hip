@@ -76,9 +76,9 @@ struct FusedArgs {
     int64_t n_dst;
     int n_rows, rep, layout;       // layout 0: node = row; 1: node = mode*n_rows + row; 2: node = row*rep + mode
     int col_shift;                 // source row = col[slot] - col_shift (window views of an absolute-time graph)
-    // frame groups (all sliding frames in one launch): destination idx -> group g = idx / group_rows, CSR row =
-    // idx % group_rows + g * group_row_shift, source row = col - col_shift - g * group_col_shift + g * group_src_stride
-    int group_rows, group_row_shift, group_col_shift, group_src_stride;
+    // optional indirections (layout 0): destination idx uses CSR row row_index[idx] and reads source rows
+    // col - col_shift + src_offset[idx] — many destination sets (sliding frames, per-frame special steps) over one CSR
+    const int32_t *row_index, *src_offset;
 };
 
 struct EdgeRows {
@@ -154,11 +154,8 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
         if (a.layout == 1) { row = idx / a.rep; node = (idx % a.rep) * (int64_t)a.n_rows + row; }
         else if (a.layout == 2) { row = idx / a.rep; }
         int src_off = -a.col_shift;
-        if (a.group_rows > 0) {
-            const int g = (int)(idx / a.group_rows);
-            row = idx - (int64_t)g * a.group_rows + (int64_t)g * a.group_row_shift;
-            src_off += g * (a.group_src_stride - a.group_col_shift);
-        }
+        if (a.row_index != nullptr) row = a.row_index[idx];
+        if (a.src_offset != nullptr) src_off += a.src_offset[idx];
         const int beg = a.rowptr[row], end = a.rowptr[row + 1];
         float2 qv = ld2(a.q, node, lane);
         qv.x *= 0.25f * kLog2e;      // head_dim ** -0.5 (layers/attention_layer.py:38), logits kept in base 2
@@ -326,17 +323,14 @@ extern "C" int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, f
 extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const float *rhat,
                                   const int32_t *rowptr, const int32_t *col, const int32_t *eid, const float *wk,
                                   const float *wv, const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows,
-                                  int64_t num_edges, int rep, int layout, int64_t col_shift, const int64_t *group,
-                                  float *out, void *stream)
+                                  int64_t num_edges, int rep, int layout, int64_t col_shift,
+                                  const int32_t *row_index, const int32_t *src_offset, float *out, void *stream)
 {
     if (n_dst < 0 || n_src < 0 || n_rows < 0 || num_edges < 0 || rep < 1) return QCN_ERR_INVALID_ARGUMENT;
     if (layout < 0 || layout > 2) return QCN_ERR_INVALID_ARGUMENT;
-    if (group != nullptr) {
-        if (layout != 0 || rep != 1 || group[0] < 1 || n_dst % group[0] != 0) return QCN_ERR_INVALID_ARGUMENT;
-        const int64_t n_groups = n_dst / group[0];
-        if (group[0] + (n_groups - 1) * group[1] > n_rows) return QCN_ERR_INVALID_ARGUMENT;
-        for (int i = 0; i < 4; ++i)
-            if (group[i] < 0 || group[i] >= ((int64_t)1 << 31)) return QCN_ERR_INVALID_ARGUMENT;
+    if (row_index != nullptr || src_offset != nullptr) {
+        if (layout != 0 || rep != 1) return QCN_ERR_INVALID_ARGUMENT;
+        if (row_index == nullptr && n_rows != n_dst) return QCN_ERR_INVALID_ARGUMENT;
     } else if (layout == 0 ? (rep != 1 || n_rows != n_dst) : n_rows * rep != n_dst) return QCN_ERR_INVALID_ARGUMENT;
     if (n_dst == 0) return QCN_OK;
     if (!q || !out || !rowptr || !wk || !wv || !bv) return QCN_ERR_INVALID_ARGUMENT;
@@ -345,7 +339,7 @@ extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v
         return QCN_ERR_UNSUPPORTED;
     if (col_shift < 0 || col_shift >= ((int64_t)1 << 31)) return QCN_ERR_INVALID_ARGUMENT;
     FusedArgs args{q, k, v, rhat, rowptr, col, eid, wk, wv, bv, out, n_dst, (int)n_rows, rep, layout, (int)col_shift,
-                   group ? (int)group[0] : 0, group ? (int)group[1] : 0, group ? (int)group[2] : 0, group ? (int)group[3] : 0};
+                   row_index, src_offset};
     // one workgroup per CU (144 KiB of LDS); every workgroup gets a contiguous chunk of >= 16 destinations
     int64_t grid = (n_dst + kWaves - 1) / kWaves;
     if (grid > 256) grid = 256;

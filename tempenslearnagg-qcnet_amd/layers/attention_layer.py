@@ -161,9 +161,9 @@ class AttentionLayer(nn.Module):
         if r is not None:
             wk, wv, bv = packs['pos']
             agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep, graph.layout,
-                                 graph.col_shift, graph.group)
+                                 graph.col_shift, graph.row_index, graph.src_offset)
         else:
-            if graph.rep != 1 or graph.col_shift != 0 or graph.group is not None:
+            if graph.rep != 1 or graph.col_shift != 0 or graph.row_index is not None or graph.src_offset is not None:
                 raise ValueError('mode-replicated / windowed graphs need a positional embedding')
             agg = ops.attn_fwd(q, k, v, None, None, graph.rowptr, graph.col, graph.eid)
         # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)

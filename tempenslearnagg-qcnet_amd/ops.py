@@ -321,11 +321,11 @@ LAYOUT_PLAIN, LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR = 0, 1, 2
 def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Tensor, rowptr: torch.Tensor,
                col: torch.Tensor, eid: Optional[torch.Tensor], wk: torch.Tensor, wv: torch.Tensor, bv: torch.Tensor,
                rep: int = 1, layout: int = LAYOUT_PLAIN, col_shift: int = 0,
-               group: Optional[Tuple[int, int, int, int]] = None) -> torch.Tensor:
+               row_index: Optional[torch.Tensor] = None, src_offset: Optional[torch.Tensor] = None) -> torch.Tensor:
     """qcn_attn_fused_f32: attention propagate with the positional projections folded into the kernel.
     ``rowptr`` may be a window (view) of a larger graph's row pointer: its entries index ``col`` / ``eid`` / ``rhat``
-    absolutely; ``col_shift`` re-bases the source ids of such a window.  ``group`` = (group_rows, group_row_shift,
-    group_col_shift, group_src_stride) runs several such windows (frames) in one launch, see include/qcnet_hip.h."""
+    absolutely; ``col_shift`` re-bases the source ids of such a window.  ``row_index`` / ``src_offset`` (int32 [n_dst])
+    give every destination its CSR row and a source re-basing of its own, see include/qcnet_hip.h."""
     dev = q.device
     n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
     n_rows = rowptr.numel() - 1
@@ -341,17 +341,22 @@ def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Te
     _require(wk, 'wk', torch.float32, dev, (C, C))
     _require(wv, 'wv', torch.float32, dev, (C, C))
     _require(bv, 'bv', torch.float32, dev, (C,))
-    garr = None
-    if group is not None:
-        if n_dst % group[0] or group[0] + (n_dst // group[0] - 1) * group[1] > n_rows:
-            raise ValueError('frame groups %s do not fit %d destinations / %d CSR rows' % (group, n_dst, n_rows))
-        garr = (ctypes.c_int64 * 4)(*[int(g) for g in group])
+    if row_index is not None or src_offset is not None:
+        if rep != 1 or layout != LAYOUT_PLAIN:
+            raise ValueError('row_index / src_offset need layout 0, rep 1')
+        if row_index is not None:
+            _require(row_index, 'row_index', torch.int32, dev, (n_dst,))
+        elif n_rows != n_dst:
+            raise ValueError('n_rows (%d) != n_dst (%d) without row_index' % (n_rows, n_dst))
+        if src_offset is not None:
+            _require(src_offset, 'src_offset', torch.int32, dev, (n_dst,))
     elif n_rows * rep != n_dst or (layout == LAYOUT_PLAIN and rep != 1):
         raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d)' % (n_rows, rep, n_dst))
     out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_attn_fused_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat), _ptr(rowptr), _ptr(col), _ptr(eid),
                                              _ptr(wk), _ptr(wv), _ptr(bv), n_dst, n_src, n_rows, num_edges, int(rep),
-                                             int(layout), int(col_shift), garr, _ptr(out), _stream(dev)), 'qcn_attn_fused_f32')
+                                             int(layout), int(col_shift), _ptr(row_index), _ptr(src_offset), _ptr(out),
+                                             _stream(dev)), 'qcn_attn_fused_f32')
     return out
 
 

@@ -28,7 +28,7 @@ class CSRGraph:
     ``i`` lives in the destination tensor: ``LAYOUT_MODE_MAJOR`` → ``m * n_rows + i``, ``LAYOUT_AGENT_MAJOR`` →
     ``i * rep + m``.  ``edge_index`` still holds the reference's replicated COO list (E = E_base * rep)."""
 
-    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid', 'rep', 'layout', 'col_shift', 'num_feature_rows', 'group')
+    __slots__ = ('edge_index', 'n_src', 'n_dst', 'rowptr', 'col', 'eid', 'rep', 'layout', 'col_shift', 'num_feature_rows', 'row_index', 'src_offset')
 
     def __init__(self, edge_index, n_src, n_dst, rowptr, col, eid, rep: int = 1, layout: int = ops.LAYOUT_PLAIN,
                  col_shift: int = 0, num_feature_rows: Optional[int] = None):
@@ -44,7 +44,9 @@ class CSRGraph:
         # ids are re-based by col_shift and the positional-feature table has num_feature_rows rows
         self.col_shift = int(col_shift)
         self.num_feature_rows = int(num_feature_rows) if num_feature_rows is not None else int(col.numel())
-        self.group = None   # (group_rows, group_row_shift, group_col_shift, group_src_stride): see frames()
+        # per-destination indirections (with_rows): CSR row and source re-basing of every destination, int32 [n_dst]
+        self.row_index = None
+        self.src_offset = None
 
     @property
     def num_base_edges(self) -> int:
@@ -88,16 +90,52 @@ class CSRGraph:
         return CSRGraph(None, n_src, row_end - row_begin, self.rowptr[row_begin:row_end + 1], self.col, self.eid,
                         col_shift=col_shift, num_feature_rows=self.num_feature_rows)
 
+    def with_rows(self, row_index: torch.Tensor, src_offset: Optional[torch.Tensor], n_src: int) -> 'CSRGraph':
+        """A new destination set over this CSR without copying it: destination ``i`` uses CSR row ``row_index[i]`` and
+        reads source rows ``col + src_offset[i]`` (None: unchanged) of an ``n_src``-row source tensor."""
+        assert self.rep == 1 and self.row_index is None and self.col_shift == 0
+        g = CSRGraph(None, n_src, row_index.numel(), self.rowptr, self.col, self.eid,
+                     num_feature_rows=self.num_feature_rows)
+        g.row_index = row_index.to(torch.int32).contiguous()
+        g.src_offset = None if src_offset is None else src_offset.to(torch.int32).contiguous()
+        return g
+
     def frames(self, n_frames: int, rows_per_frame: int, row_shift: int, n_src: int, col_shift: int = 0,
                src_stride: int = 0) -> 'CSRGraph':
         """All sliding frames of an absolute-time relation as ONE graph without copying: frame f owns destinations
         [f * rows_per_frame, (f + 1) * rows_per_frame), which are CSR rows [f * row_shift, f * row_shift + rows_per_frame);
         its source ids are col - f * col_shift + f * src_stride."""
-        assert self.rep == 1 and self.group is None
-        g = CSRGraph(None, n_src, n_frames * rows_per_frame, self.rowptr, self.col, self.eid,
-                     num_feature_rows=self.num_feature_rows)
-        g.group = (int(rows_per_frame), int(row_shift), int(col_shift), int(src_stride))
-        return g
+        dev = self.rowptr.device
+        f = torch.arange(n_frames, device=dev, dtype=torch.int64).unsqueeze(1)
+        r = torch.arange(rows_per_frame, device=dev, dtype=torch.int64).unsqueeze(0)
+        row_index = (r + f * row_shift).reshape(-1)
+        src_offset = (f * (src_stride - col_shift)).expand(n_frames, rows_per_frame).reshape(-1)
+        return self.with_rows(row_index, src_offset if (col_shift or src_stride) else None, n_src)
+
+    def validate(self) -> None:
+        """Host check (several syncs) that every destination's CSR row and every source row it reads are in range."""
+        n_rows = self.rowptr.numel() - 1
+        rows = self.row_index.long() if self.row_index is not None else torch.arange(n_rows, device=self.rowptr.device)
+        if rows.numel() and (int(rows.min()) < 0 or int(rows.max()) >= n_rows):
+            raise IndexError('row_index out of range')
+        beg, end = self.rowptr.long()[rows], self.rowptr.long()[rows + 1]
+        if rows.numel() and (int(beg.min()) < 0 or int(end.max()) > self.col.numel() or bool((end < beg).any())):
+            raise IndexError('rowptr out of range')
+        if self.col.numel() == 0 or rows.numel() == 0:
+            return
+        colf = self.col.long()
+        # per-row min / max through segment reductions on the (small) set of distinct CSR rows
+        lens = (self.rowptr.long()[1:] - self.rowptr.long()[:-1])
+        seg = torch.repeat_interleave(torch.arange(n_rows, device=colf.device), lens)
+        rmin = torch.full((n_rows,), 1 << 40, device=colf.device, dtype=torch.int64).scatter_reduce(0, seg, colf, 'amin')
+        rmax = torch.full((n_rows,), -(1 << 40), device=colf.device, dtype=torch.int64).scatter_reduce(0, seg, colf, 'amax')
+        off = (self.src_offset.long() if self.src_offset is not None else 0) - self.col_shift
+        has = end > beg
+        lo, hi = (rmin[rows] + off)[has], (rmax[rows] + off)[has]
+        if lo.numel() and (int(lo.min()) < 0 or int(hi.max()) >= self.n_src):
+            raise IndexError('source rows out of range: [%d, %d] for n_src %d' % (int(lo.min()), int(hi.max()), self.n_src))
+        if self.eid is not None and self.eid.numel() and (int(self.eid.min()) < 0 or int(self.eid.max()) >= self.num_feature_rows):
+            raise IndexError('eid out of range')
 
     def replicate(self, rep: int, layout: int, edge_index: Optional[torch.Tensor] = None) -> 'CSRGraph':
         """The same edge list for ``rep`` mode copies of every destination row (see class docstring).
