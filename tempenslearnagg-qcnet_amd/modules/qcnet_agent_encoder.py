@@ -233,6 +233,118 @@ class QCNetAgentEncoder(nn.Module):
             x_a = x_a.view(F, T, A, C).transpose(1, 2)                                   # (f, a, t)
         return x_a.reshape(F * A, T, C)
 
+    def streaming_plan(self, needed_from: int):
+        """Which (frame-relative) steps of a later frame cannot be taken from the long run.
+
+        The temporal attention is causal with a reach of ``time_span`` steps, the other two relations do not mix time,
+        and the only frame-dependent input is the zero motion vector of a window's first step (reference :99).  So the
+        output of layer l at offset d = u - f inside frame f >= 1 equals the long run's value at absolute step u as soon
+        as d > l * time_span.  ``D[l]`` lists the offsets of layer l's output that are (a) needed — by the consumer
+        (offsets >= ``needed_from``) for the last layer, as a source or as the destination's own row by ``D[l + 1]``
+        otherwise — and (b) not yet equal to the long run."""
+        S, NL, T = self.time_span, self.num_layers, self.num_historical_steps
+        special = lambda l, d: d <= l * S
+        D = [None] * (NL + 1)
+        D[NL] = [d for d in range(int(needed_from), T) if special(NL, d)]
+        for l in range(NL, 0, -1):
+            need = set()
+            for d in D[l]:
+                need.update(dp for dp in range(max(0, d - S), d) if special(l - 1, dp))
+                if special(l - 1, d):
+                    need.add(d)
+            D[l - 1] = sorted(need)
+        return D
+
+    @torch.no_grad()
+    def forward_frames_streaming(self, data, map_enc: Mapping[str, torch.Tensor], cache, needed_from: int) -> torch.Tensor:
+        """``x_a`` [F * A, T, C] of all frames like :meth:`forward_frames`, but only steps >= ``needed_from`` of every
+        frame are produced (the decoder reads the last num_t2m_steps steps, modules/qcnet_decoder.py:143,151; the other
+        entries are left uninitialised), and the work the frames share is done once:
+
+        * one LONG RUN of the layers over the absolute steps [0, T + F - 1) of all agents (frame 0 is its prefix),
+        * per later frame only the few steps of :meth:`streaming_plan` (for the reference configuration one step per
+          layer: offsets 0 / 10 / 20), appended to the long run's rows as extra destinations of the same launches.
+        Row for row the arithmetic is that of ``forward(data, map_enc, first_shift + f)``."""
+        T, C, S, NL = self.num_historical_steps, self.hidden_dim, self.time_span, self.num_layers
+        A, P = int(data['agent']['num_nodes']), int(data['map_polygon']['num_nodes'])
+        F, n_abs = cache['n_frames'], cache['n_abs']
+        dev = cache['x_main'].device
+        D = self.streaming_plan(needed_from)
+        if any(d > 0 for d in D[0]):
+            raise AssertionError('layer-0 features differ from the long run at the first step only')
+        NA = A * n_abs
+        x_pl = map_enc['x_pl'][:, 0]
+        i64 = dict(device=dev, dtype=torch.int64)
+        a_ids = torch.arange(A, **i64)
+        frames = torch.arange(1, F, **i64)                                            # frames with special steps
+
+        xl = torch.cat([cache['x_first'][:, :1], cache['x_main'][:, 1:]], dim=1)      # [A, n_abs, C], (a, u) order
+        xs = cache['x_first'][:, 1:].transpose(0, 1).unsqueeze(1) if D[0] else None   # [F-1, |D0|, A, C]
+        t_src, t_dst, t_agent = cache['t_src'], cache['t_dst'], cache['t_agent']
+        E_abs = t_src.numel()
+        can_src, can_dst = t_agent * n_abs + t_src, t_agent * n_abs + t_dst
+        for l in range(1, NL + 1):
+            Dp, Dl = D[l - 1], D[l]
+            n_prev, n_own = (F - 1) * len(Dp) * A, (F - 1) * len(Dl) * A
+            parts = [xl.reshape(NA, C)]
+            src_all, dst_all, eid_all = [can_src], [can_dst], [torch.arange(E_abs, **i64)]
+            if n_prev:
+                parts.append(xs.reshape(n_prev, C))
+            if n_own:
+                # the destinations' own rows (residual / query input): previous-layer value at (f, d)
+                own = []
+                for d in Dl:
+                    own.append(xs[:, Dp.index(d)] if d in Dp else xl[:, frames + d].transpose(0, 1))   # [F-1, A, C]
+                parts.append(torch.stack(own, dim=1).reshape(n_own, C))
+                # their temporal edges: absolute edges into step f + d whose source lies inside frame f
+                d_vec = torch.tensor(Dl, **i64)
+                u_dst = (frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1)                          # [J]
+                f_of = frames.unsqueeze(1).expand(-1, len(Dl)).reshape(-1)
+                hit = (t_dst.unsqueeze(0) == u_dst.unsqueeze(1)) & (t_src.unsqueeze(0) >= f_of.unsqueeze(1))
+                j_sel, e_sel = hit.nonzero(as_tuple=True)
+                ag, fj = t_agent[e_sel], f_of[j_sel]
+                dp = t_src[e_sel] - fj                                                                  # source offset
+                pos_in_prev = torch.full((T + 1,), -1, **i64)
+                if Dp:
+                    pos_in_prev[torch.tensor(Dp, **i64)] = torch.arange(len(Dp), **i64)
+                slot = pos_in_prev[dp.clamp(0, T)]
+                is_special = dp <= (l - 1) * S
+                src_special = NA + ((fj - 1) * max(len(Dp), 1) + slot.clamp_min(0)) * A + ag
+                src_all.append(torch.where(is_special, src_special, ag * n_abs + t_src[e_sel]))
+                dst_all.append(NA + n_prev + j_sel * A + ag)
+                eid_all.append(e_sel)
+            n_all = NA + n_prev + n_own
+            g_t = CSRGraph.from_edge_index(torch.stack([torch.cat(src_all), torch.cat(dst_all)]), n_all, n_all,
+                                           validate=False)
+            g_t.eid = torch.cat(eid_all).to(torch.int32)[g_t.eid.long()]
+            g_t.num_feature_rows = cache['r_t'].rhat.size(0)
+            y = self.t_attn_layers[l - 1](torch.cat(parts) if len(parts) > 1 else parts[0], cache['r_t'], g_t)
+
+            # spatial relations: time-major long-run rows, then the special rows (f, d, a)
+            yc = y[:NA].view(A, n_abs, C).transpose(0, 1).reshape(NA, C)
+            if n_own:
+                u_rows = ((frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1, 1) * A + a_ids.unsqueeze(0)).reshape(-1)
+                row_index = torch.cat([torch.arange(NA, **i64), u_rows])
+                blk = NA + torch.arange(n_own, **i64)
+                src_offset = torch.cat([torch.zeros(NA, **i64), blk - blk % A - (u_rows - u_rows % A)])
+                x2 = torch.cat([yc, y[NA + n_prev:]])
+                g_pl2a = cache['g_pl2a'].with_rows(row_index, None, P)
+                g_a2a = cache['g_a2a'].with_rows(row_index, src_offset, NA + n_own)
+            else:
+                x2, g_pl2a, g_a2a = yc, cache['g_pl2a'], cache['g_a2a']
+            z = self.pl2a_attn_layers[l - 1]((x_pl, x2), cache['r_pl2a'], g_pl2a)
+            z = self.a2a_attn_layers[l - 1](z, cache['r_a2a'], g_a2a)
+            xl = z[:NA].view(n_abs, A, C).transpose(0, 1)                                                # (a, u) view
+            xs = z[NA:].view(F - 1, len(Dl), A, C) if n_own else None
+
+        out = torch.empty(F, A, T, C, dtype=xl.dtype, device=dev)
+        tail = torch.arange(int(needed_from), T, **i64)
+        steps = torch.arange(F, **i64).unsqueeze(1) + tail.unsqueeze(0)                                   # [F, Mt]
+        out[:, :, int(needed_from):] = xl[:, steps].permute(1, 0, 2, 3)
+        for i, d in enumerate(D[NL]):
+            out[1:, :, d] = xs[:, i]
+        return out.view(F * A, T, C)
+
     def forward(self, data, map_enc: Mapping[str, torch.Tensor], time_shift: int, cache=None,
                 return_edge_index: Optional[bool] = None) -> Dict[str, torch.Tensor]:
         """``cache``: result of :meth:`precompute` for a range of time shifts containing ``time_shift`` (same output,

@@ -134,7 +134,9 @@ class QCNetDecoder(nn.Module):
         head_m = agent['heading'][:, T - 1 + ts].contiguous()
         dev = pos_m.device
 
-        x_t = scene_enc['x_a'].reshape(-1, C)
+        # only the last num_t2m_steps steps are ever sources of the time->mode attention (:143): project those alone
+        Mt = min(self.num_t2m_steps, T)
+        x_t = scene_enc['x_a'][:, T - Mt:].reshape(-1, C)
         x_pl = scene_enc['x_pl'][:, T - 1]          # [P, C]; reference tiles it K times (:150)
         x_a = scene_enc['x_a'][:, -1]               # [A, C]; reference tiles it K times (:151)
         m = self.mode_emb.weight.repeat(A, 1)
@@ -151,7 +153,9 @@ class QCNetDecoder(nn.Module):
         # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
         r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=True))
         ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
-        g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False).replicate(
+        g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
+        col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
+        g_t2m = g_t2m.remap_sources(col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt), A * Mt).replicate(
             K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
 
         pos_pl = data['map_polygon']['position'][:, :2].contiguous()

@@ -42,6 +42,11 @@ class TempEnsLearnAgg(nn.Module):
         # The ten frames are independent given the shared work, so they run as ONE ten-fold batch: every layer is
         # one launch over all frames instead of ten small ones.
         self.batch_frames = share_map_encoding
+        # Consecutive frames also share almost all of the agent encoder's LAYER outputs: its temporal attention is
+        # causal with a reach of time_span steps, so a frame differs from one long run over all absolute steps only
+        # in its first num_layers * time_span steps, of which the decoder reads at most a few
+        # (modules/qcnet_agent_encoder.py forward_frames_streaming).
+        self.stream_encoder = share_map_encoding
 
     def forward(self, data, time_shift: int, map_enc=None, agent_cache=None
                 ) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:
@@ -64,7 +69,10 @@ class TempEnsLearnAgg(nn.Module):
         A = int(data['agent']['num_nodes'])
         map_enc = enc.map_encoder(data)
         cache = enc.agent_encoder.precompute(data, 1, n_f)
-        x_a = enc.agent_encoder.forward_frames(data, map_enc, cache)                       # [F * A, T, C]
+        if self.stream_encoder:
+            x_a = enc.agent_encoder.forward_frames_streaming(data, map_enc, cache, T - min(dec.num_t2m_steps, T))
+        else:
+            x_a = enc.agent_encoder.forward_frames(data, map_enc, cache)                   # [F * A, T, C]
         frames = frame_batch(data, 1, n_f, T + 2)
         x_pl = map_enc['x_pl'][:, 0]
         scene = {'x_a': x_a, 'x_pl': x_pl.repeat(n_f, 1).unsqueeze(1).expand(-1, T, -1)}

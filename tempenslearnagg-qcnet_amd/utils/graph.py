@@ -90,6 +90,13 @@ class CSRGraph:
         return CSRGraph(None, n_src, row_end - row_begin, self.rowptr[row_begin:row_end + 1], self.col, self.eid,
                         col_shift=col_shift, num_feature_rows=self.num_feature_rows)
 
+    def remap_sources(self, col: torch.Tensor, n_src: int) -> 'CSRGraph':
+        """The same edges reading from a re-indexed source tensor (``col``: new source row per CSR slot)."""
+        g = CSRGraph(self.edge_index, n_src, self.n_dst, self.rowptr, col.to(torch.int32).contiguous(), self.eid,
+                     self.rep, self.layout, self.col_shift, self.num_feature_rows)
+        g.row_index, g.src_offset = self.row_index, self.src_offset
+        return g
+
     def with_rows(self, row_index: torch.Tensor, src_offset: Optional[torch.Tensor], n_src: int) -> 'CSRGraph':
         """A new destination set over this CSR without copying it: destination ``i`` uses CSR row ``row_index[i]`` and
         reads source rows ``col + src_offset[i]`` (None: unchanged) of an ``n_src``-row source tensor."""

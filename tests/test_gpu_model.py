@@ -147,6 +147,34 @@ def test_frame_reuse_cache_equals_per_frame_encoding(cfg_name, ids):
             enc.agent_encoder(batch, map_enc, 11, cache=cache)
 
 
+@pytest.mark.parametrize('cfg_name,ids,needed_from', [('tiny', [0, 1, 2], 20), ('cfg1', [4], 20), ('tiny', [5], 3),
+                                                      ('tiny', [6, 7], 45)])
+def test_streaming_encoder_equals_frame_batched_encoder(cfg_name, ids, needed_from):
+    """forward_frames_streaming (one long run over the absolute steps + the few per-frame special steps) against
+    forward_frames (every frame in full) on every entry it promises: steps >= needed_from of all ten frames.
+    needed_from = 20 is the decoder's (T - num_t2m_steps: one special step per layer); 3 makes 18 steps per frame
+    special in the last layer, 45 none at all."""
+    cfg = config_scene(cfg_name)
+    model = _model(cfg).to(DEV)
+    batch = make_batch(ids, **cfg['scene']).to(DEV)
+    enc = model.base_model.encoder
+    plan = enc.agent_encoder.streaming_plan(needed_from)
+    assert plan[0] in ([0], []) and all(d <= 10 * l for l, ds in enumerate(plan) for d in ds)
+    if needed_from == 20:
+        assert plan == [[0], [10], [20]]
+    if needed_from == 45:
+        assert plan == [[], [], []]
+    with torch.no_grad():
+        map_enc = enc.map_encoder(batch)
+        cache = enc.agent_encoder.precompute(batch, 1, 10)
+        want = enc.agent_encoder.forward_frames(batch, map_enc, cache)
+        got = enc.agent_encoder.forward_frames_streaming(batch, map_enc, cache, needed_from)
+    assert got.shape == want.shape
+    assert rel_err(got[:, needed_from:], want[:, needed_from:]) < 1e-6
+    # frame 0 is the long run's prefix and most rows are bitwise the per-frame values
+    assert (got[:, needed_from:] == want[:, needed_from:]).float().mean() > 0.5
+
+
 def test_scenarios_are_independent_full_size():
     """Size-independent property at the full bench batch shape: a scenario's prediction does not depend on
     what else is in the batch (scenario sharding across GPUs relies on it)."""
