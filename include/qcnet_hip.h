@@ -190,9 +190,16 @@ int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj
 
 /* K10 — recurrent half of the decoder's nn.GRU(128,128) trajectory embedder (modules/qcnet_decoder.py:86-88,257),
  * final hidden state only.  gi_r / gi_z / gi_n [n_seq * n_steps, 128]: the input half W_i* x_t + b_i* for row
- * seq * n_steps + t (one qcn_ln_linear_f32 call without LayerNorm); whh_t [128, 384] = weight_hh_l0^T (gate order r, z, n);
- * b_hh [384]; h0 [128] (broadcast to every sequence); h_out [n_seq, 128]. */
-int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh_t,
+ * seq * n_steps + t (one qcn_ln_linear_f32 call without LayerNorm); b_hh [384]; h0 [128] (broadcast to every sequence);
+ * h_out [n_seq, 128].  whh, by matmul mode:
+ *   exact: [128, 384] = weight_hh_l0^T (gate order r, z, n), fp32;
+ *   split: qcn_gru_pack_floats() floats = f16 hi / lo fragments [gate][wave w][k16-step j][plane][lane][8] of
+ *          W'_g[32 w + (lane & 31)][16 j + 8 (lane >> 5) + i] (W'_g = gate matrix scaled by a power of two to
+ *          [2^14, 2^15)), followed by {s_r, 1/s_r, s_z, 1/s_z, s_n, 1/s_n, s_h, 1/s_h}; s_h = power of two with
+ *          max(1, max|h0|) * s_h <= 2^14 (the hidden state never leaves [-max(1, max|h0|), +...]).
+ *          Host packer: ops.pack_gru_whh. */
+size_t qcn_gru_pack_floats(void);
+int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh,
                 const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, void *stream);
 
 /* K6 — y = (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine; the layer-independent half

@@ -87,7 +87,143 @@ __global__ __launch_bounds__(256) void gru_kernel(const float *__restrict__ gi_r
     }
 }
 
+// ---- split-f16 mode (include/qcnet_hip.h: QCN_MATMUL_SPLIT_F16) --------------------------------------------------------
+// Same recurrence, transposed like the chain kernels (W_hh is the MFMA A operand, the 32 sequences are N): wave w owns
+// output features [32w, 32w+32) of the three gates.  Its W_hh slice lives in 192 VGPRs as hi / lo f16 fragments of
+// v_mfma_f32_32x32x16_f16 (3 gates x 8 k16-steps x 2 planes x 4 registers), a step is 72 MFMAs (hi*hi + hi*lo + lo*hi)
+// instead of 192 fp32 ones.  The hidden state is bounded by construction, |h_t| <= max(1, max|h_0|) (a convex
+// combination of tanh values and h_{t-1}), so its hi / lo split uses ONE fixed power-of-two scale and no row reduction;
+// the fp32 state itself stays in the owner's registers (the recurrence h = (1 - z) n + z h is evaluated in fp32), only
+// the matmul operand is split.  Waves exchange the split state through a padded, double-buffered LDS image
+// [plane][sequence][128 f16 + 8 pad] (row stride 272 B: the 16-byte fragment reads of 16 consecutive lanes fall on 16
+// distinct bank groups).  gi rows of step t + 1 are requested before the MFMAs of step t.
+using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using half4v = __attribute__((ext_vector_type(4))) _Float16;
+using half2v = __attribute__((ext_vector_type(2))) _Float16;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kHRow = kC + 8;               // halfs per LDS row
+constexpr int kGruPackFloats = 3 * 4 * 8 * 2 * 64 * 4;   // [gate][wave][k16-step][plane][lane] x 16 B
+constexpr int kGruScaleFloats = 8;          // {s_r, 1/s_r, s_z, 1/s_z, s_n, 1/s_n, s_h, 1/s_h}
+
+__global__ __launch_bounds__(256) void gru_split_kernel(const float *__restrict__ gi_r, const float *__restrict__ gi_z,
+                                                        const float *__restrict__ gi_n, const float *__restrict__ wpack,
+                                                        const float *__restrict__ b_hh, const float *__restrict__ h0,
+                                                        int64_t n_seq, int n_steps, float *__restrict__ h_out)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 s_h[2][2][kRowsPerWave][kHRow];   // [buffer][plane][seq][feature]
+    const int tid = threadIdx.x, lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t seq = (int64_t)blockIdx.x * kRowsPerWave + n;
+    const bool valid = seq < n_seq;
+    const int64_t grow = (valid ? seq : n_seq - 1) * n_steps;
+    const float *scales = wpack + kGruPackFloats;
+    const float s_hid = scales[6];
+    const float u_r = scales[1] * scales[7], u_z = scales[3] * scales[7], u_n = scales[5] * scales[7];
+
+    half8 wf[3][8][2];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                wf[g][j][p] = __builtin_bit_cast(half8, *reinterpret_cast<const f32x4 *>(
+                    wpack + ((((size_t)(g * 4 + wave) * 8 + j) * 2 + p) * 64 + lane) * 4));
+
+    // this lane's 16 output features: 32 wave + 8 q + 4 hh + i  (register 4 q + i)
+    float bhr[16], bhz[16], bhn[16], hreg[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f0 = 32 * wave + 8 * q + 4 * hh;
+        const f32x4 br = *reinterpret_cast<const f32x4 *>(b_hh + f0);
+        const f32x4 bz = *reinterpret_cast<const f32x4 *>(b_hh + kC + f0);
+        const f32x4 bn = *reinterpret_cast<const f32x4 *>(b_hh + 2 * kC + f0);
+        const f32x4 hv = *reinterpret_cast<const f32x4 *>(h0 + f0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { bhr[4 * q + i] = br[i]; bhz[4 * q + i] = bz[i]; bhn[4 * q + i] = bn[i]; hreg[4 * q + i] = hv[i]; }
+    }
+    auto publish = [&](int buf) {   // split the lane's 16 state values and store them as 4-feature groups
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half4v hi4, lo4;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const float x0 = hreg[4 * q + i] * s_hid, x1 = hreg[4 * q + i + 1] * s_hid;
+                const half2v a = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+                const half2v b = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0 - (float)a[0], x1 - (float)a[1]));
+                hi4[i] = a[0]; hi4[i + 1] = a[1]; lo4[i] = b[0]; lo4[i + 1] = b[1];
+            }
+            const int f0 = 32 * wave + 8 * q + 4 * hh;
+            *reinterpret_cast<half4v *>(&s_h[buf][0][n][f0]) = hi4;
+            *reinterpret_cast<half4v *>(&s_h[buf][1][n][f0]) = lo4;
+        }
+    };
+    publish(0);
+
+    f32x4 gnx[3][4];   // gi of the next step
+    auto request = [&](int t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t off = (size_t)(grow + t) * kC + 32 * wave + 8 * q + 4 * hh;
+            gnx[0][q] = *reinterpret_cast<const f32x4 *>(gi_r + off);
+            gnx[1][q] = *reinterpret_cast<const f32x4 *>(gi_z + off);
+            gnx[2][q] = *reinterpret_cast<const f32x4 *>(gi_n + off);
+        }
+    };
+    request(0);
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = 0; t < n_steps; ++t) {
+        f32x4 gcur[3][4];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gcur[g][q] = gnx[g][q];
+        request(t + 1 < n_steps ? t + 1 : t);
+        f32x16 ar, az, an;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ar[r] = 0.f; az[r] = 0.f; an[r] = 0.f; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const half8 bh = *reinterpret_cast<const half8 *>(&s_h[t & 1][0][n][16 * j + 8 * hh]);
+            const half8 bl = *reinterpret_cast<const half8 *>(&s_h[t & 1][1][n][16 * j + 8 * hh]);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][j][0], bh, ar, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][j][0], bh, az, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[2][j][0], bh, an, 0, 0, 0);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][j][0], bl, ar, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][j][0], bl, az, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[2][j][0], bl, an, 0, 0, 0);
+            ar = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[0][j][1], bh, ar, 0, 0, 0);
+            az = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[1][j][1], bh, az, 0, 0, 0);
+            an = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[2][j][1], bh, an, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float pr = fmaf(ar[r], u_r, bhr[r]), pz = fmaf(az[r], u_z, bhz[r]), pn = fmaf(an[r], u_n, bhn[r]);
+            const float rg = 1.0f / (1.0f + expf(-(gcur[0][r >> 2][r & 3] + pr)));
+            const float zg = 1.0f / (1.0f + expf(-(gcur[1][r >> 2][r & 3] + pz)));
+            const float ng = tanhf(fmaf(rg, pn, gcur[2][r >> 2][r & 3]));
+            hreg[r] = fmaf(zg, hreg[r] - ng, ng);          // (1 - z) * n + z * h
+        }
+        publish((t + 1) & 1);
+        __syncthreads();
+    }
+    if (valid) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = hreg[4 * q + i];
+            *reinterpret_cast<f32x4 *>(h_out + seq * kC + 32 * wave + 8 * q + 4 * hh) = o;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" size_t qcn_gru_pack_floats(void) { return (size_t)kGruPackFloats + kGruScaleFloats; }
 
 extern "C" int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh_t,
                            const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, void *stream)
@@ -97,7 +233,11 @@ extern "C" int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi
     if (!gi_r || !gi_z || !gi_n || !whh_t || !b_hh || !h0 || !h_out) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
     const unsigned grid = (unsigned)((n_seq + kRowsPerWave - 1) / kRowsPerWave);
-    hipLaunchKernelGGL(gru_kernel, dim3(grid), dim3(256), 0, s, gi_r, gi_z, gi_n, whh_t, b_hh, h0, n_seq, n_steps, h_out);
+    if (qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16)
+        hipLaunchKernelGGL(gru_split_kernel, dim3(grid), dim3(256), 0, s, gi_r, gi_z, gi_n, whh_t, b_hh, h0, n_seq, n_steps,
+                           h_out);
+    else
+        hipLaunchKernelGGL(gru_kernel, dim3(grid), dim3(256), 0, s, gi_r, gi_z, gi_n, whh_t, b_hh, h0, n_seq, n_steps, h_out);
     QCN_CHECK_LAUNCH();
     return QCN_OK;
 }

@@ -96,7 +96,7 @@ class QCNetDecoder(nn.Module):
             C = self.hidden_dim
             with torch.no_grad():
                 wih_t = ops.pack_chain_matrices(list(gru.weight_ih_l0.view(3, C, C)))
-                self._gru_pack = (wih_t, gru.bias_ih_l0.view(3, C).contiguous(), gru.weight_hh_l0.t().contiguous(),
+                self._gru_pack = (wih_t, gru.bias_ih_l0.view(3, C).contiguous(), ops.pack_gru_whh(gru.weight_hh_l0, self.traj_emb_h0),
                                   gru.bias_hh_l0.contiguous(), self.traj_emb_h0.reshape(-1).contiguous())
             self._gru_key = key
         return self._gru_pack

@@ -295,17 +295,58 @@ def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_r
     return out
 
 
+def pack_gru_whh(weight_hh: torch.Tensor, h0: torch.Tensor, mode: Optional[int] = None) -> torch.Tensor:
+    """``nn.GRU.weight_hh_l0`` ([384, 128], gates r, z, n) in the layout qcn_gru_f32 expects for the matmul mode in force
+    (include/qcnet_hip.h, K10)."""
+    if mode is None:
+        mode = matmul_mode()
+    w = weight_hh.detach().float()
+    if tuple(w.shape) != (3 * C, C):
+        raise ValueError('weight_hh must be [384, 128]')
+    if mode == MATMUL_EXACT_F32:
+        return w.t().contiguous()
+    dev = w.device
+    planes, scales = [], []
+    for g in range(3):
+        wg = w[g * C:(g + 1) * C]
+        mx = float(wg.abs().max())
+        e = int(torch.frexp(wg.abs().max())[1]) if mx > 0 else 0
+        sc = 2.0 ** (15 - e)
+        ws = wg * sc
+        hi = ws.half()
+        planes.append(torch.stack([hi, (ws - hi.float()).half()]))          # [p, out, in]
+        scales += [sc, 1.0 / sc]
+    bound = max(1.0, float(h0.detach().abs().max()))
+    e_h = int(torch.frexp(torch.tensor(bound))[1])                          # bound <= 2^e_h
+    scales += [2.0 ** (14 - e_h), 2.0 ** (e_h - 14)]
+    planes = torch.stack(planes)                                            # [g, p, out, in]
+    lane = torch.arange(64, device=dev)
+    out_idx = (32 * torch.arange(4, device=dev).view(4, 1, 1) + (lane & 31).view(1, 64, 1)).view(1, 4, 1, 1, 64, 1)
+    in_idx = (16 * torch.arange(8, device=dev).view(8, 1, 1) + 8 * (lane >> 5).view(1, 64, 1)
+              + torch.arange(8, device=dev).view(1, 1, 8)).view(1, 1, 8, 1, 64, 8)
+    g_idx = torch.arange(3, device=dev).view(3, 1, 1, 1, 1, 1)
+    p_idx = torch.arange(2, device=dev).view(1, 1, 1, 2, 1, 1)
+    frag = planes[g_idx, p_idx, out_idx, in_idx]                            # [g, w, j, p, lane, i]
+    packed = frag.contiguous().view(-1).view(torch.float32)
+    out = torch.cat([packed, torch.tensor(scales, dtype=torch.float32, device=dev)])
+    assert out.numel() == int(_lib.lib().qcn_gru_pack_floats())
+    return out.contiguous()
+
+
 def gru_last_hidden(x_seq: torch.Tensor, n_steps: int, wih_t: torch.Tensor, b_ih: torch.Tensor, whh_t: torch.Tensor,
                     b_hh: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
     """Final hidden state of a 1-layer GRU(128, 128) over ``n_steps`` steps.  ``x_seq`` [n_seq * n_steps, 128] with
-    row = seq * n_steps + t; ``wih_t`` = pack_chain_matrices of the three gate matrices (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` [128, 384];
+    row = seq * n_steps + t; ``wih_t`` = pack_chain_matrices of the three gate matrices (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` = pack_gru_whh(weight_hh_l0, h0);
     ``b_hh`` [384]; ``h0`` [128].  Input half: one qcn_ln_linear_f32 launch; recurrence: one qcn_gru_f32 launch."""
     dev = x_seq.device
     _require(x_seq, 'x_seq', torch.float32, dev, (None, C))
     if x_seq.size(0) % n_steps:
         raise ValueError('x_seq rows (%d) not a multiple of n_steps (%d)' % (x_seq.size(0), n_steps))
     n_seq = x_seq.size(0) // n_steps
-    _require(whh_t, 'whh_t', torch.float32, dev, (C, 3 * C))
+    if matmul_mode() == MATMUL_EXACT_F32:
+        _require(whh_t, 'whh_t', torch.float32, dev, (C, 3 * C))
+    else:
+        _require(whh_t, 'whh_t', torch.float32, dev, (int(_lib.lib().qcn_gru_pack_floats()),))
     _require(b_hh, 'b_hh', torch.float32, dev, (3 * C,))
     _require(h0, 'h0', torch.float32, dev, (C,))
     (gi_r, gi_z, gi_n), _ = ln_linear(x_seq, None, None, wih_t, b_ih)

@@ -10,6 +10,13 @@ from tempenslearnagg_qcnet_amd.utils.graph import CSRGraph
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
+
+
+@pytest.fixture
+def restore_matmul_mode():
+    mode = ops.matmul_mode()
+    yield
+    ops.set_matmul_mode(mode)
 TOL = 1e-4   # BASELINE.json north_star: fp32 outputs within 1e-4 relative
 
 
@@ -195,8 +202,11 @@ def test_attn_fused_mode_replication_equals_explicit_graph(layout):
     assert rel_err(got, want) < 2e-5
 
 
-def test_gru_kernel_matches_torch_gru():
-    """qcn_gru_f32 + input GEMM against torch.nn.GRU (CPU fp32), ragged sequence count (tail block)."""
+@pytest.mark.parametrize('mode,h0_scale', [(0, 0.3), (1, 0.3), (1, 5.0)])
+def test_gru_kernel_matches_torch_gru(mode, h0_scale, restore_matmul_mode):
+    """qcn_gru_f32 + input GEMM against torch.nn.GRU (CPU fp32), ragged sequence count (tail block), in both matmul
+    modes; h0_scale 5.0 puts the initial state outside [-1, 1] (the split kernel's fixed state scale must follow it)."""
+    ops.set_matmul_mode(mode)
     torch.manual_seed(11)
     gru = torch.nn.GRU(128, 128).eval()
     with torch.no_grad():
@@ -204,22 +214,15 @@ def test_gru_kernel_matches_torch_gru():
             p.copy_(torch.randn_like(p) * 0.12)
     n_seq, n_steps = 77, 60
     seq = torch.randn(n_steps, n_seq, 128)
-    h0 = torch.randn(128) * 0.3
+    h0 = torch.randn(128) * h0_scale
     with torch.no_grad():
         want = gru(seq, h0.view(1, 1, 128).repeat(1, n_seq, 1))[1].squeeze(0)
     x = seq.transpose(0, 1).reshape(-1, 128).contiguous().to(DEV)          # row = seq * n_steps + t
     wih_t = ops.pack_chain_matrices(list(gru.weight_ih_l0.detach().view(3, 128, 128).to(DEV)))
     got = ops.gru_last_hidden(x, n_steps, wih_t, gru.bias_ih_l0.detach().view(3, 128).contiguous().to(DEV),
-                              gru.weight_hh_l0.detach().t().contiguous().to(DEV), gru.bias_hh_l0.detach().to(DEV),
+                              ops.pack_gru_whh(gru.weight_hh_l0.detach().to(DEV), h0.to(DEV)), gru.bias_hh_l0.detach().to(DEV),
                               h0.to(DEV))
     assert rel_err(got, want) < 1e-5
-
-
-@pytest.fixture
-def restore_matmul_mode():
-    mode = ops.matmul_mode()
-    yield
-    ops.set_matmul_mode(mode)
 
 
 @pytest.mark.gpu
