@@ -65,6 +65,7 @@ def main() -> None:
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg4', 'tiny'])
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-exact-pass', action='store_true', help='skip the extra timing in the exact-fp32-MFMA mode')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -111,7 +112,7 @@ def main() -> None:
     # The same steps with the chain kernels in their exact-fp32-MFMA mode (include/qcnet_hip.h: QCN_MATMUL_EXACT_F32),
     # reported beside `value` (which is measured in the default split-f16 mode, whose matmul error is not larger).
     exact_ms = None
-    if world == 1:
+    if world == 1 and not args.no_exact_pass:
         mode = ops.matmul_mode()
         ops.set_matmul_mode(ops.MATMUL_EXACT_F32)
         with torch.no_grad():

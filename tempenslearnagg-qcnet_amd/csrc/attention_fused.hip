@@ -26,6 +26,7 @@
 // `rep`/`layout`: consecutive waves take the K modes of one CSR row, so rhat_e is fetched from HBM once and served
 // to the other K-1 waves from L1/L2.
 #include "common.hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -36,6 +37,7 @@ constexpr int kU = 2;                  // edges per iteration
 constexpr float kLog2e = 1.4426950408889634f;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;   // v_pk_fma_f32 operands
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -106,11 +108,15 @@ __device__ __forceinline__ void load_rows(const FusedArgs &a, const int (&src)[k
     }
 }
 
-template <bool HAS_EID>
-__global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
+// R = number of mode copies of one CSR row that a wave carries together (1, or a divisor of `rep`): the edge rows are
+// loaded and handed over through LDS once per edge and serve R softmax streams — the vector-memory, L1 and LDS traffic
+// per (edge, mode) visit drops R-fold, only the FMAs remain per visit.  R > 1 runs 8 waves of up to 256 registers.
+template <bool HAS_EID, int R>
+__global__ __launch_bounds__(R == 1 ? 1024 : 512) void attn_fused_kernel(FusedArgs a)
 {
+    constexpr int kW = R == 1 ? kWaves : kWaves / 2;
     // one array (see the chunk swizzle above): [0, 128) rows of wk, [128, 256) rows of wv, then kU staging rows per wave
-    __shared__ __attribute__((aligned(16))) float lds[(2 * kC + kWaves * kU) * kC];
+    __shared__ __attribute__((aligned(16))) float lds[(2 * kC + kW * kU) * kC];
     float *const s_wk = lds, *const s_wv = lds + kC * kC;
 
     const int tid = threadIdx.x;
@@ -119,7 +125,7 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
     const int h = lane >> 3, sub = lane & 7;
     float *const s_stage = lds + (2 * kC + wave * kU) * kC;
 
-    for (int i = tid; i < kC * 32; i += 1024) {
+    for (int i = tid; i < kC * 32; i += 64 * kW) {
         const int o = i >> 5, c = i & 31;
         const int pc = c ^ (2 * ((o >> 4) & 1) + (c >> 4));
         *reinterpret_cast<f32x4 *>(s_wk + o * kC + 4 * pc) = *reinterpret_cast<const f32x4 *>(a.wk + o * kC + 4 * c);
@@ -140,30 +146,47 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
 #pragma unroll
     for (int i = 0; i < 4; ++i) q_off[i] = 4 * ((4 * h + i) ^ (h >> 2));
 
-    // contiguous chunk of destinations per workgroup (XCD-contiguous through the block remap)
+    // contiguous chunk of work items per workgroup (XCD-contiguous through the block remap); a work item = one
+    // destination (R == 1) or R consecutive modes of one CSR row
+    const int64_t n_items = a.n_dst / R;
+    const int groups = a.rep / R;                 // mode groups per CSR row (R > 1)
     const int64_t nb = gridDim.x;
     const int64_t lb = qcn_xcd_remap(blockIdx.x, gridDim.x);
-    const int64_t per = (a.n_dst + nb - 1) / nb;
+    const int64_t per = (n_items + nb - 1) / nb;
     const int64_t begin = lb * per;
-    const int64_t end_idx = begin + per < a.n_dst ? begin + per : a.n_dst;
+    const int64_t end_idx = begin + per < n_items ? begin + per : n_items;
     const float2 bias = ld2(a.bv, 0, lane);
     const bool b0 = (sub & 1) != 0, b1 = (sub & 2) != 0, b2 = (sub & 4) != 0;
 
-    for (int64_t idx = begin + wave; idx < end_idx; idx += kWaves) {
-        int64_t row = idx, node = idx;
-        if (a.layout == 1) { row = idx / a.rep; node = (idx % a.rep) * (int64_t)a.n_rows + row; }
-        else if (a.layout == 2) { row = idx / a.rep; }
+    for (int64_t idx = begin + wave; idx < end_idx; idx += kW) {
+        int64_t row = idx, node[R];
+        if (R == 1) {
+            node[0] = idx;
+            if (a.layout == 1) { row = idx / a.rep; node[0] = (idx % a.rep) * (int64_t)a.n_rows + row; }
+            else if (a.layout == 2) { row = idx / a.rep; }
+        } else {
+            row = idx / groups;
+            const int m0 = (int)(idx - row * groups) * R;
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                node[r] = a.layout == 1 ? (int64_t)(m0 + r) * a.n_rows + row : row * a.rep + m0 + r;
+        }
         int src_off = -a.col_shift;
         if (a.row_index != nullptr) row = a.row_index[idx];
         if (a.src_offset != nullptr) src_off += a.src_offset[idx];
         const int beg = a.rowptr[row], end = a.rowptr[row + 1];
-        float2 qv = ld2(a.q, node, lane);
-        qv.x *= 0.25f * kLog2e;      // head_dim ** -0.5 (layers/attention_layer.py:38), logits kept in base 2
-        qv.y *= 0.25f * kLog2e;
-
-        float m = -INFINITY, l = 0.f;
-        float2 accv = make_float2(0.f, 0.f);
-        float2 proj = make_float2(0.f, 0.f);
+        float2 qv[R];
+        float m[R], l[R];
+        float2 accv[R], proj[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            qv[r] = ld2(a.q, node[r], lane);
+            qv[r].x *= 0.25f * kLog2e;      // head_dim ** -0.5 (layers/attention_layer.py:38), logits kept in base 2
+            qv[r].y *= 0.25f * kLog2e;
+            m[r] = -INFINITY; l[r] = 0.f;
+            accv[r] = make_float2(0.f, 0.f);
+            proj[r] = make_float2(0.f, 0.f);
+        }
 
         if (end > beg) {
             int src[kU], e[kU];
@@ -173,27 +196,32 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
             load_indices<HAS_EID>(a, beg + kU, end, src_off, src, e);
 
             // ---- prologue: utilde^h[c] = sum_d wk[16h + d][c] * q'^h[d] for the lane's 16-channel slice
-            *reinterpret_cast<float2 *>(s_stage + st_off) = qv;
-            wave_lds_fence();
-            float qh[16];
+            f32x2 u[R][8], s[R][8];   // the slice as channel pairs: packed fp32 FMAs (two channels per instruction)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4 *>(s_stage + q_off[i]);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) qh[4 * i + jj] = t4[jj];
-            }
-            wave_lds_fence();
-            float u[16], s[16];
-#pragma unroll
-            for (int c = 0; c < 16; ++c) { u[c] = 0.f; s[c] = 0.f; }
-#pragma unroll
-            for (int d = 0; d < 16; ++d)
+            for (int r = 0; r < R; ++r) {
+                *reinterpret_cast<float2 *>(s_stage + st_off) = qv[r];
+                wave_lds_fence();
+                float qh[16];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_wk + w_off[i] + d * kC);
+                    const f32x4 t4 = *reinterpret_cast<const f32x4 *>(s_stage + q_off[i]);
 #pragma unroll
-                    for (int jj = 0; jj < 4; ++jj) u[4 * i + jj] = fmaf(w4[jj], qh[d], u[4 * i + jj]);
+                    for (int jj = 0; jj < 4; ++jj) qh[4 * i + jj] = t4[jj];
                 }
+                wave_lds_fence();
+#pragma unroll
+                for (int c = 0; c < 8; ++c) { u[r][c] = f32x2{0.f, 0.f}; s[r][c] = f32x2{0.f, 0.f}; }
+#pragma unroll
+                for (int d = 0; d < 16; ++d) {
+                    const f32x2 qd = {qh[d], qh[d]};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_wk + w_off[i] + d * kC);
+                        u[r][2 * i] = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, qd, u[r][2 * i]);
+                        u[r][2 * i + 1] = __builtin_elementwise_fma(f32x2{w4[2], w4[3]}, qd, u[r][2 * i + 1]);
+                    }
+                }
+            }
 
             // ---- edge loop
             for (int j = beg; j < end; j += kU) {
@@ -202,87 +230,100 @@ __global__ __launch_bounds__(1024) void attn_fused_kernel(FusedArgs a)
                 load_rows(a, src, e, lane, nxt);                                    // rows of iteration j + kU
                 load_indices<HAS_EID>(a, j + 2 * kU, end, src_off, src, e);         // indices of iteration j + 2 kU
                 wave_lds_fence();
-                float r16[kU][16], sim[kU];
-                float smax = -INFINITY;
+                f32x2 r16[kU][8];
 #pragma unroll
-                for (int t = 0; t < kU; ++t) {
+                for (int t = 0; t < kU; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const f32x4 t4 = *reinterpret_cast<const f32x4 *>(s_stage + t * kC + r_off[i]);
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) r16[t][4 * i + jj] = t4[jj];
+                        r16[t][2 * i] = f32x2{t4[0], t4[1]};
+                        r16[t][2 * i + 1] = f32x2{t4[2], t4[3]};
                     }
-                    float p0 = qv.x * cur.k[t].x, p1 = qv.y * cur.k[t].y;
-#pragma unroll
-                    for (int c = 0; c < 16; c += 2) {
-                        p0 = fmaf(u[c], r16[t][c], p0);
-                        p1 = fmaf(u[c + 1], r16[t][c + 1], p1);
-                    }
-                    const float part = head_sum(p0 + p1);
-                    sim[t] = (j + t < end) ? part : -INFINITY;
-                    smax = fmaxf(smax, sim[t]);
-                }
                 wave_lds_fence();                                  // staging rows are free again
-                const float mn = fmaxf(m, smax);
-                if (!__all(mn == m)) {                             // running max moved for some head: rescale
-                    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-                    l *= alpha; accv.x *= alpha; accv.y *= alpha;
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) s[c] *= alpha;
-                    m = mn;
-                }
+                for (int r = 0; r < R; ++r) {
+                    float sim[kU];
+                    float smax = -INFINITY;
 #pragma unroll
-                for (int t = 0; t < kU; ++t) {
-                    const float pe = __builtin_amdgcn_exp2f(sim[t] - m);
-                    l += pe;
-                    accv.x = fmaf(pe, cur.v[t].x, accv.x);
-                    accv.y = fmaf(pe, cur.v[t].y, accv.y);
+                    for (int t = 0; t < kU; ++t) {
+                        f32x2 pa = f32x2{qv[r].x, qv[r].y} * f32x2{cur.k[t].x, cur.k[t].y}, pb = f32x2{0.f, 0.f};
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) s[c] = fmaf(pe, r16[t][c], s[c]);
+                        for (int c = 0; c < 8; c += 2) {
+                            pa = __builtin_elementwise_fma(u[r][c], r16[t][c], pa);
+                            pb = __builtin_elementwise_fma(u[r][c + 1], r16[t][c + 1], pb);
+                        }
+                        pa += pb;
+                        const float part = head_sum(pa[0] + pa[1]);
+                        sim[t] = (j + t < end) ? part : -INFINITY;
+                        smax = fmaxf(smax, sim[t]);
+                    }
+                    const float mn = fmaxf(m[r], smax);
+                    if (!__all(mn == m[r])) {                          // running max moved for some head: rescale
+                        const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
+                        l[r] *= alpha; accv[r].x *= alpha; accv[r].y *= alpha;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) s[r][c] *= alpha;
+                        m[r] = mn;
+                    }
+#pragma unroll
+                    for (int t = 0; t < kU; ++t) {
+                        const float pe = __builtin_amdgcn_exp2f(sim[t] - m[r]);
+                        l[r] += pe;
+                        accv[r].x = fmaf(pe, cur.v[t].x, accv[r].x);
+                        accv[r].y = fmaf(pe, cur.v[t].y, accv[r].y);
+                        const f32x2 pe2 = {pe, pe};
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) s[r][c] = __builtin_elementwise_fma(pe2, r16[t][c], s[r][c]);
+                    }
                 }
                 cur = nxt;
             }
 
             // ---- epilogue: out^h[d] = sum_c wv[16h + d][c] * s^h[c]: in-lane partial over the slice, then a
             // reduce-scatter over the 8 lanes of the head that leaves d = 2 sub, 2 sub + 1 on lane sub
-            float part[16];
 #pragma unroll
-            for (int d = 0; d < 16; ++d) {
-                float p0 = 0.f, p1 = 0.f;
+            for (int r = 0; r < R; ++r) {
+                float part[16];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_wv + w_off[i] + d * kC);
-                    p0 = fmaf(w4[0], s[4 * i], p0);
-                    p1 = fmaf(w4[1], s[4 * i + 1], p1);
-                    p0 = fmaf(w4[2], s[4 * i + 2], p0);
-                    p1 = fmaf(w4[3], s[4 * i + 3], p1);
+                for (int d = 0; d < 16; ++d) {
+                    f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4 *>(s_wv + w_off[i] + d * kC);
+                        p0 = __builtin_elementwise_fma(f32x2{w4[0], w4[1]}, s[r][2 * i], p0);
+                        p1 = __builtin_elementwise_fma(f32x2{w4[2], w4[3]}, s[r][2 * i + 1], p1);
+                    }
+                    p0 += p1;
+                    part[d] = p0[0] + p0[1];
                 }
-                part[d] = p0 + p1;
-            }
-            float r1[8], r2[4];
+                float r1[8], r2[4];
 #pragma unroll
-            for (int d = 0; d < 8; ++d) {       // partner 7 - sub (opposite bit 2): keep d with bit 3 == own bit 2
-                const float keep = b2 ? part[d + 8] : part[d], give = b2 ? part[d] : part[d + 8];
-                r1[d] = keep + dpp_mov<kDppMirror8>(give);
-            }
+                for (int d = 0; d < 8; ++d) {       // partner 7 - sub (opposite bit 2): keep d with bit 3 == own bit 2
+                    const float keep = b2 ? part[d + 8] : part[d], give = b2 ? part[d] : part[d + 8];
+                    r1[d] = keep + dpp_mov<kDppMirror8>(give);
+                }
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {       // partner sub ^ 2: keep d with bit 2 == own bit 1
-                const float keep = b1 ? r1[d + 4] : r1[d], give = b1 ? r1[d] : r1[d + 4];
-                r2[d] = keep + dpp_mov<kDppXor2>(give);
-            }
-            {                                   // partner sub ^ 1: keep d with bit 1 == own bit 0
-                const float k0 = b0 ? r2[2] : r2[0], g0 = b0 ? r2[0] : r2[2];
-                const float k1 = b0 ? r2[3] : r2[1], g1 = b0 ? r2[1] : r2[3];
-                proj.x = k0 + dpp_mov<kDppXor1>(g0);
-                proj.y = k1 + dpp_mov<kDppXor1>(g1);
+                for (int d = 0; d < 4; ++d) {       // partner sub ^ 2: keep d with bit 2 == own bit 1
+                    const float keep = b1 ? r1[d + 4] : r1[d], give = b1 ? r1[d] : r1[d + 4];
+                    r2[d] = keep + dpp_mov<kDppXor2>(give);
+                }
+                {                                   // partner sub ^ 1: keep d with bit 1 == own bit 0
+                    const float k0 = b0 ? r2[2] : r2[0], g0 = b0 ? r2[0] : r2[2];
+                    const float k1 = b0 ? r2[3] : r2[1], g1 = b0 ? r2[1] : r2[3];
+                    proj[r].x = k0 + dpp_mov<kDppXor1>(g0);
+                    proj[r].y = k1 + dpp_mov<kDppXor1>(g1);
+                }
             }
         }
-        const float inv = 1.0f / (l + 1e-16f);        // PyG softmax denominator
-        const float asum = l * inv;                   // A_i^h: 1 for non-empty segments, 0 for empty ones
-        float2 o2;
-        o2.x = fmaf(inv, proj.x + accv.x, asum * bias.x);
-        o2.y = fmaf(inv, proj.y + accv.y, asum * bias.y);
-        *reinterpret_cast<float2 *>(a.out + node * kC + 2 * lane) = o2;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float inv = 1.0f / (l[r] + 1e-16f);     // PyG softmax denominator
+            const float asum = l[r] * inv;                // A_i^h: 1 for non-empty segments, 0 for empty ones
+            float2 o2;
+            o2.x = fmaf(inv, proj[r].x + accv[r].x, asum * bias.x);
+            o2.y = fmaf(inv, proj[r].y + accv[r].y, asum * bias.y);
+            *reinterpret_cast<float2 *>(a.out + node[r] * kC + 2 * lane) = o2;
+        }
     }
 }
 
@@ -340,15 +381,19 @@ extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v
     if (col_shift < 0 || col_shift >= ((int64_t)1 << 31)) return QCN_ERR_INVALID_ARGUMENT;
     FusedArgs args{q, k, v, rhat, rowptr, col, eid, wk, wv, bv, out, n_dst, (int)n_rows, rep, layout, (int)col_shift,
                    row_index, src_offset};
-    // one workgroup per CU (144 KiB of LDS); every workgroup gets a contiguous chunk of >= 16 destinations
-    int64_t grid = (n_dst + kWaves - 1) / kWaves;
+    // one workgroup per CU (136-144 KiB of LDS); every workgroup gets a contiguous chunk of work items.  Mode-replicated
+    // graphs carry 3 (or 2) modes of a row per wave.
+    int R = rep % 3 == 0 ? 3 : (rep % 2 == 0 ? 2 : 1);
+    if (const char *env = getenv("QCN_ATTN_R")) { const int want = atoi(env); if (want >= 1 && want <= 3 && rep % want == 0) R = want; }
+    const int waves = R == 1 ? kWaves : kWaves / 2;
+    int64_t grid = (n_dst / R + waves - 1) / waves;
     if (grid > 256) grid = 256;
     hipStream_t s = qcn_stream(stream);
     void *token = qcn_prof_begin(QCN_PROF_ATTN_FUSED, 1552.0 * (double)num_edges * (double)rep + 1024.0 * (double)n_dst, s);
-    if (eid)
-        hipLaunchKernelGGL((attn_fused_kernel<true>), dim3((unsigned)grid), dim3(1024), 0, s, args);
-    else
-        hipLaunchKernelGGL((attn_fused_kernel<false>), dim3((unsigned)grid), dim3(1024), 0, s, args);
+#define QCN_LAUNCH(E, RR) hipLaunchKernelGGL((attn_fused_kernel<E, RR>), dim3((unsigned)grid), dim3(64 * (RR == 1 ? kWaves : kWaves / 2)), 0, s, args)
+    if (eid) { if (R == 3) QCN_LAUNCH(true, 3); else if (R == 2) QCN_LAUNCH(true, 2); else QCN_LAUNCH(true, 1); }
+    else     { if (R == 3) QCN_LAUNCH(false, 3); else if (R == 2) QCN_LAUNCH(false, 2); else QCN_LAUNCH(false, 1); }
+#undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
