@@ -66,7 +66,11 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
                 // ((x * f) * 2) * pi in fp32, the reference's evaluation order (:58)
                 const float ang = __fmul_rn(__fmul_rn(__fmul_rn(xv, f4[j]), 2.0f), 3.14159265358979323846f);
                 float sn, cs;
+#ifdef QCN_FAKE_SINCOS
+                sn = ang * 0.001f; cs = ang * 0.002f;
+#else
                 sincosf(ang, &sn, &cs);
+#endif
                 ft[s >> 4][s & 15] = cs;
                 ft[2 + (s >> 4)][s & 15] = sn;
             }
