@@ -188,6 +188,16 @@ size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
                       const float *pack, int64_t n_rows, float *out, void *stream);
 
+/* A5 — up to three MLPLayer heads (layers/mlp_layer.py:20-36: Linear(128,128) -> LayerNorm -> ReLU -> Linear(128,out_h),
+ * out_h <= 128) over the same rows in one launch (the decoder's to_loc_* / to_scale_* / to_pi heads,
+ * modules/qcnet_decoder.py:229-233,270-280).  x [n_rows,128]; y_h [n_rows, out_dims[h]] dense; out_dims: HOST array.
+ * pack (qcn_mlp_heads_pack_floats(n_heads) floats): per head the two chain-packed matrices [mlp.0.weight, mlp.3.weight
+ * with its rows zero-padded to 128], then per head [mlp.0.bias, mlp.1.weight, mlp.1.bias, mlp.3.bias zero-padded], then
+ * the scale table (32 floats). */
+size_t qcn_mlp_heads_pack_floats(int n_heads);
+int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pack, int n_heads, const int *out_dims,
+                      float *y0, float *y1, float *y2, void *stream);
+
 /* K10 — recurrent half of the decoder's nn.GRU(128,128) trajectory embedder (modules/qcnet_decoder.py:86-88,257),
  * final hidden state only.  gi_r / gi_z / gi_n [n_seq * n_steps, 128]: the input half W_i* x_t + b_i* for row
  * seq * n_steps + t (one qcn_ln_linear_f32 call without LayerNorm); b_hh [384]; h0 [128] (broadcast to every sequence);

@@ -27,6 +27,7 @@
 // so k-step s is one conflict-free ds_read_b128 per lane feeding four MFMAs (one per output tile).
 #pragma once
 #include "common.hip.h"
+#include <cstdlib>
 
 namespace qcn_chain {
 
@@ -269,6 +270,7 @@ __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restri
 __host__ inline int pick_waves(int64_t n_rows, bool split, int n_cus = 256)
 {
     (void)split;
+    if (const char *env = getenv("QCN_CHAIN_WAVES")) { const int w = atoi(env); if (w == 2 || w == 4 || w == 8) return w; }
     int best = 8;
     double best_cost = 1e300;
     for (int w = 8; w >= 2; w >>= 1) {

@@ -151,7 +151,111 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     }
 }
 
+// A5 — MLPLayer heads (layers/mlp_layer.py:20-36: Linear(128,128) -> LayerNorm -> ReLU -> Linear(128,out)) of the decoder
+// (modules/qcnet_decoder.py:117-138,229-233,270-280): up to three heads that read the same row in one launch.
+// pack: 2 chain-packed matrices per head [W1_h, W2_h (out rows zero-padded to 128)], then per head the plain vectors
+// [b1, ln_g, ln_b, b2 (zero-padded)] (4 * 128), then the scale table (32 floats).  Outputs are dense [n_rows, out_h].
+constexpr int kMlpMaxHeads = 3, kMlpVecs = 4 * kC, kMlpScales = 32;
+
+struct MlpHeads {
+    float *y[kMlpMaxHeads];
+    int out_dim[kMlpMaxHeads];
+    int n_heads;
+};
+
+template <bool SPLIT, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__restrict__ x, int64_t n_rows,
+                                                               const float *__restrict__ pack, MlpHeads hd)
+{
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
+    const bool valid = row < n_rows;
+    const int64_t rowc = valid ? row : n_rows - 1;
+    const int n_mats = 2 * hd.n_heads;
+    const float *vecs = pack + (size_t)n_mats * kMatFloats;
+    const float *msc = vecs + hd.n_heads * kMlpVecs;
+
+    stage_matrix<WAVES>(pack, wlds, wave, lane);
+    f32x16 xv[4];
+    load_row(xv, x, rowc, h);
+    Operand<SPLIT> xo;
+    make_operand(xo, xv);
+#pragma unroll 1
+    for (int i = 0; i < hd.n_heads; ++i) {
+        const float *vec = vecs + i * kMlpVecs;
+        f32x16 acc[4];
+        load_feature_vec(acc, vec, h);
+        sync_for_stage();
+        gemm<WAVES>(acc, xo, wlds + ((2 * i) & 1) * kMatVec4, msc + 4 * i, lane, pack + (size_t)(2 * i + 1) * kMatFloats,
+                    wlds + ((2 * i + 1) & 1) * kMatVec4, wave);
+        layer_norm<true, true>(acc, vec + kC, vec + 2 * kC, h, 1e-5f);
+        Operand<SPLIT> hid;
+        make_operand(hid, acc);
+        load_feature_vec(acc, vec + 3 * kC, h);
+        sync_for_stage();
+        gemm<WAVES>(acc, hid, wlds + ((2 * i + 1) & 1) * kMatVec4, msc + 4 * i + 2, lane,
+                    2 * i + 2 < n_mats ? pack + (size_t)(2 * i + 2) * kMatFloats : nullptr, wlds + ((2 * i + 2) & 1) * kMatVec4,
+                    wave);
+        if (valid) {
+            const int od = hd.out_dim[i];
+            float *y = hd.y[i] + row * od;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f0 = 32 * t + 8 * q + 4 * h;
+                    if ((od & 3) == 0) {
+                        if (f0 < od) {
+                            f32x4 v;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = acc[t][4 * q + j];
+                            *reinterpret_cast<f32x4 *>(y + f0) = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (f0 + j < od) y[f0 + j] = acc[t][4 * q + j];
+                    }
+                }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" size_t qcn_mlp_heads_pack_floats(int n_heads)
+{
+    return n_heads < 1 || n_heads > kMlpMaxHeads ? 0 : (size_t)2 * n_heads * kMatFloats + (size_t)n_heads * kMlpVecs + kMlpScales;
+}
+
+extern "C" int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pack, int n_heads, const int *out_dims,
+                                 float *y0, float *y1, float *y2, void *stream)
+{
+    if (n_rows < 0 || n_heads < 1 || n_heads > kMlpMaxHeads || !out_dims) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_rows == 0) return QCN_OK;
+    if (!x || !pack || !y0 || (n_heads > 1 && !y1) || (n_heads > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
+    MlpHeads hd{};
+    float *ys[kMlpMaxHeads] = {y0, y1, y2};
+    for (int i = 0; i < n_heads; ++i) {
+        if (out_dims[i] < 1 || out_dims[i] > kC) return QCN_ERR_UNSUPPORTED;
+        hd.y[i] = ys[i];
+        hd.out_dim[i] = out_dims[i];
+    }
+    hd.n_heads = n_heads;
+    hipStream_t s = qcn_stream(stream);
+    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
+    const int waves = pick_waves(n_rows, split);
+    const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * n_heads * 2 * 2.0 * kMatFloats, s);
+#define QCN_LAUNCH(S, W) hipLaunchKernelGGL((mlp_heads_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, pack, hd)
+    QCN_CHAIN_DISPATCH(split, waves);
+#undef QCN_LAUNCH
+    const bool ok = hipGetLastError() == hipSuccess;
+    qcn_prof_end(token, s);
+    return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
+}
 
 extern "C" size_t qcn_attn_post_pack_floats(void) { return (size_t)kPostMats * kMatFloats + kPostVecs + kPostScales; }
 

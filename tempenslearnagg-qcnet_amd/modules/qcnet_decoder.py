@@ -101,6 +101,10 @@ class QCNetDecoder(nn.Module):
             self._gru_key = key
         return self._gru_pack
 
+    def _head_cache(self, name: str) -> dict:
+        caches = self.__dict__.setdefault('_mlp_head_caches', {})
+        return caches.setdefault(name, {})
+
     # hook: TemporalAggregate sums the stored mode queries of the earlier frames into the new ones here
     def _fuse_modes(self, m: torch.Tensor, temporal_m: Optional[torch.Tensor]) -> torch.Tensor:
         return m
@@ -185,8 +189,9 @@ class QCNetDecoder(nn.Module):
         scales: List[torch.Tensor] = []
         for _ in range(self.num_recurrent_steps):
             m = self._cross_stack('propose', m, *graphs)
-            locs.append(self.to_loc_propose_pos(m))
-            scales.append(self.to_scale_propose_pos(m))
+            loc, scale = MLPLayer.fused([self.to_loc_propose_pos, self.to_scale_propose_pos], m, self._head_cache('propose'))
+            locs.append(loc)
+            scales.append(scale)
         loc_propose_pos = torch.cumsum(torch.cat(locs, dim=-1).view(-1, K, Tf, OD), dim=-2)
         scale_propose_pos = torch.cumsum(F.elu(torch.cat(scales, dim=-1).view(-1, K, Tf, OD), alpha=1.0) + 1.0,
                                          dim=-2) + 0.1
@@ -200,9 +205,11 @@ class QCNetDecoder(nn.Module):
         m = self._fuse_modes(m, temporal_m)
         m = self._cross_stack('refine', m, *graphs)
 
-        loc_refine_pos = self.to_loc_refine_pos(m).view(-1, K, Tf, OD) + loc_propose_pos.detach()
-        scale_refine_pos = F.elu(self.to_scale_refine_pos(m).view(-1, K, Tf, OD), alpha=1.0) + 1.0 + 0.1
-        pi = self.to_pi(m).squeeze(-1)
+        loc_ref, scale_ref, pi = MLPLayer.fused([self.to_loc_refine_pos, self.to_scale_refine_pos, self.to_pi], m,
+                                                self._head_cache('refine'))
+        loc_refine_pos = loc_ref.view(-1, K, Tf, OD) + loc_propose_pos.detach()
+        scale_refine_pos = F.elu(scale_ref.view(-1, K, Tf, OD), alpha=1.0) + 1.0 + 0.1
+        pi = pi.squeeze(-1)
         return {
             'loc_propose_pos': loc_propose_pos,
             'scale_propose_pos': scale_propose_pos,

@@ -295,6 +295,37 @@ def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_r
     return out
 
 
+def pack_mlp_heads(heads) -> torch.Tensor:
+    """Pack for qcn_mlp_heads_f32 from a list of (w1 [128,128], b1, ln_w, ln_b, w2 [out,128], b2 [out]) tuples."""
+    mats, vecs = [], []
+    for w1, b1, ln_w, ln_b, w2, b2 in heads:
+        out = w2.size(0)
+        if tuple(w1.shape) != (C, C) or w2.size(1) != C or not 1 <= out <= C:
+            raise ValueError('MLP head shapes: Linear(128,128) -> Linear(128,<=128)')
+        w2p = w2.new_zeros(C, C)
+        w2p[:out] = w2
+        b2p = b2.new_zeros(C)
+        b2p[:out] = b2
+        mats += [w1, w2p]
+        vecs += [b1, ln_w, ln_b, b2p]
+    packed, scales = pack_chain_set(mats)
+    return torch.cat([packed.reshape(-1)] + [v.detach().reshape(-1).float() for v in vecs] + [scale_table(scales)]).contiguous()
+
+
+def mlp_heads(x: torch.Tensor, pack: torch.Tensor, out_dims) -> list:
+    """qcn_mlp_heads_f32: [y_h [n, out_dims[h]]] for up to three MLPLayer heads over the same rows."""
+    dev = x.device
+    n, n_heads = x.size(0), len(out_dims)
+    _require(x, 'x', torch.float32, dev, (n, C))
+    _require(pack, 'pack', torch.float32, dev, (int(_lib.lib().qcn_mlp_heads_pack_floats(n_heads)),))
+    ys = [torch.empty(n, int(o), dtype=torch.float32, device=dev) for o in out_dims]
+    yp = [_ptr(y) for y in ys] + [None] * (3 - n_heads)
+    od = (ctypes.c_int * n_heads)(*[int(o) for o in out_dims])
+    _lib.check(_lib.lib().qcn_mlp_heads_f32(_ptr(x), n, _ptr(pack), n_heads, od, yp[0], yp[1], yp[2], _stream(dev)),
+               'qcn_mlp_heads_f32')
+    return ys
+
+
 def pack_gru_whh(weight_hh: torch.Tensor, h0: torch.Tensor, mode: Optional[int] = None) -> torch.Tensor:
     """``nn.GRU.weight_hh_l0`` ([384, 128], gates r, z, n) in the layout qcn_gru_f32 expects for the matmul mode in force
     (include/qcnet_hip.h, K10)."""
