@@ -188,6 +188,15 @@ size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
                       const float *pack, int64_t n_rows, float *out, void *stream);
 
+/* G0 / K7 — relative geometry of an edge list (utils/geometry.py:19-23 angle_between_2d_vectors, :47-51 wrap_angle, and
+ * their call sites modules/qcnet_map_encoder.py:121-128, qcnet_agent_encoder.py:133-139,161-176, qcnet_decoder.py:161-206):
+ *   dp = pos_src[src[e]] - pos_dst[dst[e]];  out[e] = [|dp|, angle(heading_dst, dp), wrap(head_src - head_dst) (, extra[e])]
+ * pos_* [n, pos_stride_*] fp32 (x, y first), head_* [n] fp32, src / dst / extra int64 [n_edges] (extra may be NULL: 3
+ * columns instead of 4).  The caller guarantees the indices are in range (they come from the graph builders). */
+int qcn_rel_geometry_f32(const float *pos_src, int pos_stride_src, const float *pos_dst, int pos_stride_dst,
+                         const float *head_src, const float *head_dst, const int64_t *src, const int64_t *dst,
+                         const int64_t *extra, int64_t n_edges, float *out, void *stream);
+
 /* A5 — up to three MLPLayer heads (layers/mlp_layer.py:20-36: Linear(128,128) -> LayerNorm -> ReLU -> Linear(128,out_h),
  * out_h <= 128) over the same rows in one launch (the decoder's to_loc_* / to_scale_* / to_pi heads,
  * modules/qcnet_decoder.py:229-233,270-280).  x [n_rows,128]; y_h [n_rows, out_dims[h]] dense; out_dims: HOST array.

@@ -3,6 +3,7 @@ from typing import Optional
 
 import torch
 
+from .. import ops
 from ..data import Batch
 from ..utils.geometry import angle_between_2d_vectors, wrap_angle
 
@@ -23,6 +24,13 @@ def rel_geometry(pos_src: torch.Tensor, pos_dst: torch.Tensor, head_src: torch.T
     the relative-geometry vector every relation feeds its FourierEmbedding
     (modules/qcnet_map_encoder.py:121-128, modules/qcnet_agent_encoder.py:133-139,161-166,171-176,
     modules/qcnet_decoder.py:161-167,183-188,201-206)."""
+    return ops.rel_geometry(pos_src.contiguous(), pos_dst.contiguous(), head_src.contiguous(), head_dst.contiguous(),
+                            edge_index, extra)
+
+
+def rel_geometry_torch(pos_src: torch.Tensor, pos_dst: torch.Tensor, head_src: torch.Tensor, head_dst: torch.Tensor,
+                       edge_index: torch.Tensor, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The same vector from torch ops with the reference's helpers (the form the kernel is tested against)."""
     src, dst = edge_index[0], edge_index[1]
     rel_pos = pos_src[src] - pos_dst[dst]
     hd = head_dst[dst]

@@ -295,6 +295,31 @@ def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_r
     return out
 
 
+def rel_geometry(pos_src: torch.Tensor, pos_dst: torch.Tensor, head_src: torch.Tensor, head_dst: torch.Tensor,
+                 edge_index: torch.Tensor, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qcn_rel_geometry_f32: [E, 3 (4 with ``extra``)] relative-geometry rows of an edge list ([2, E] int64, row 0 indexes
+    the ``*_src`` tensors, row 1 the ``*_dst`` tensors; the edge lists come from the graph builders and are in range)."""
+    dev = pos_src.device
+    _require(pos_src, 'pos_src', torch.float32, dev, (None, None))
+    _require(pos_dst, 'pos_dst', torch.float32, dev, (None, None))
+    _require(head_src, 'head_src', torch.float32, dev, (pos_src.size(0),))
+    _require(head_dst, 'head_dst', torch.float32, dev, (pos_dst.size(0),))
+    if pos_src.size(1) < 2 or pos_dst.size(1) < 2:
+        raise ValueError('positions need x and y columns')
+    if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
+        raise ValueError('edge_index must be [2, E] int64')
+    e = edge_index.size(1)
+    src, dst = edge_index[0].contiguous(), edge_index[1].contiguous()
+    if extra is not None:
+        extra = extra.to(torch.int64).contiguous()
+        _require(extra, 'extra', torch.int64, dev, (e,))
+    out = torch.empty(e, 4 if extra is not None else 3, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_rel_geometry_f32(_ptr(pos_src), pos_src.size(1), _ptr(pos_dst), pos_dst.size(1), _ptr(head_src),
+                                               _ptr(head_dst), _ptr(src), _ptr(dst), _ptr(extra), e, _ptr(out), _stream(dev)),
+               'qcn_rel_geometry_f32')
+    return out
+
+
 def pack_mlp_heads(heads) -> torch.Tensor:
     """Pack for qcn_mlp_heads_f32 from a list of (w1 [128,128], b1, ln_w, ln_b, w2 [out,128], b2 [out]) tuples."""
     mats, vecs = [], []

@@ -130,3 +130,34 @@ def test_dense_to_sparse_and_coalesce_match_oracle():
     # lexicographically sorted and unique
     key = wi[0] * 30 + wi[1]
     assert bool((key[1:] > key[:-1]).all())
+
+
+@pytest.mark.gpu
+def test_rel_geometry_kernel_matches_reference_helpers():
+    """qcn_rel_geometry_f32 against the torch form built from the reference-named helpers (utils/geometry.py), including
+    zero displacement (the signed-zero case: atan2 must give 0, not pi), angles on the wrap boundary and the optional
+    fourth column."""
+    import math
+    from tempenslearnagg_qcnet_amd import ops
+    from tempenslearnagg_qcnet_amd.modules._common import rel_geometry_torch
+    torch.manual_seed(5)
+    ns, nd, e = 700, 300, 20000
+    pos_s = (torch.randn(ns, 3, device='cuda:0') * 40).contiguous()
+    pos_d = (torch.randn(nd, 2, device='cuda:0') * 40).contiguous()
+    head_s = torch.empty(ns, device='cuda:0').uniform_(-math.pi, math.pi)
+    head_d = torch.empty(nd, device='cuda:0').uniform_(-math.pi, math.pi)
+    head_d[:4] = torch.tensor([0.0, math.pi, -math.pi, math.pi / 2], device='cuda:0')
+    ei = torch.stack([torch.randint(0, ns, (e,), device='cuda:0'), torch.randint(0, nd, (e,), device='cuda:0')])
+    ei[0, :50] = torch.arange(50, device='cuda:0')                  # distinct sources for the
+    pos_s[ei[0, :50], :2] = pos_d[ei[1, :50]]                     # zero-displacement edges
+    head_s[ei[0, 50:80]] = head_d[ei[1, 50:80]]                    # zero heading difference
+    extra = torch.randint(-30, 1, (e,), device='cuda:0')
+    for ex in (None, extra):
+        want = rel_geometry_torch(pos_s[:, :2], pos_d, head_s, head_d, ei, ex)   # the kernel takes the row stride
+        got = ops.rel_geometry(pos_s, pos_d, head_s, head_d, ei, ex)
+        assert got.shape == want.shape
+        assert torch.equal(got[:50, 1], torch.zeros(50, device='cuda:0'))       # angle of a zero vector is +0
+        assert float((got - want).abs().max()) < 2e-6
+        assert (got == want).float().mean() > 0.99
+    empty = ops.rel_geometry(pos_s, pos_d, head_s, head_d, ei[:, :0])
+    assert empty.shape == (0, 3)
