@@ -112,9 +112,9 @@ __device__ __forceinline__ void load_rows(const FusedArgs &a, const int (&src)[k
 // loaded and handed over through LDS once per edge and serve R softmax streams — the vector-memory, L1 and LDS traffic
 // per (edge, mode) visit drops R-fold, only the FMAs remain per visit.  R > 1 runs 8 waves of up to 256 registers.
 template <bool HAS_EID, int R>
-__global__ __launch_bounds__(R == 1 ? 1024 : 512) void attn_fused_kernel(FusedArgs a)
+__global__ __launch_bounds__(R == 1 ? 1024 : (R <= 3 ? 512 : 256)) void attn_fused_kernel(FusedArgs a)
 {
-    constexpr int kW = R == 1 ? kWaves : kWaves / 2;
+    constexpr int kW = R == 1 ? kWaves : (R <= 3 ? kWaves / 2 : kWaves / 4);
     // one array (see the chunk swizzle above): [0, 128) rows of wk, [128, 256) rows of wv, then kU staging rows per wave
     __shared__ __attribute__((aligned(16))) float lds[(2 * kC + kW * kU) * kC];
     float *const s_wk = lds, *const s_wv = lds + kC * kC;
@@ -384,15 +384,15 @@ extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v
     // one workgroup per CU (136-144 KiB of LDS); every workgroup gets a contiguous chunk of work items.  Mode-replicated
     // graphs carry 3 (or 2) modes of a row per wave.
     int R = rep % 3 == 0 ? 3 : (rep % 2 == 0 ? 2 : 1);
-    if (const char *env = getenv("QCN_ATTN_R")) { const int want = atoi(env); if (want >= 1 && want <= 3 && rep % want == 0) R = want; }
-    const int waves = R == 1 ? kWaves : kWaves / 2;
+    if (const char *env = getenv("QCN_ATTN_R")) { const int want = atoi(env); if ((want == 1 || want == 2 || want == 3 || want == 6) && rep % want == 0) R = want; }
+    const int waves = R == 1 ? kWaves : (R <= 3 ? kWaves / 2 : kWaves / 4);
     int64_t grid = (n_dst / R + waves - 1) / waves;
     if (grid > 256) grid = 256;
     hipStream_t s = qcn_stream(stream);
     void *token = qcn_prof_begin(QCN_PROF_ATTN_FUSED, 1552.0 * (double)num_edges * (double)rep + 1024.0 * (double)n_dst, s);
-#define QCN_LAUNCH(E, RR) hipLaunchKernelGGL((attn_fused_kernel<E, RR>), dim3((unsigned)grid), dim3(64 * (RR == 1 ? kWaves : kWaves / 2)), 0, s, args)
-    if (eid) { if (R == 3) QCN_LAUNCH(true, 3); else if (R == 2) QCN_LAUNCH(true, 2); else QCN_LAUNCH(true, 1); }
-    else     { if (R == 3) QCN_LAUNCH(false, 3); else if (R == 2) QCN_LAUNCH(false, 2); else QCN_LAUNCH(false, 1); }
+#define QCN_LAUNCH(E, RR) hipLaunchKernelGGL((attn_fused_kernel<E, RR>), dim3((unsigned)grid), dim3(64 * (RR == 1 ? kWaves : (RR <= 3 ? kWaves / 2 : kWaves / 4))), 0, s, args)
+    if (eid) { if (R == 6) QCN_LAUNCH(true, 6); else if (R == 3) QCN_LAUNCH(true, 3); else if (R == 2) QCN_LAUNCH(true, 2); else QCN_LAUNCH(true, 1); }
+    else     { if (R == 6) QCN_LAUNCH(false, 6); else if (R == 3) QCN_LAUNCH(false, 3); else if (R == 2) QCN_LAUNCH(false, 2); else QCN_LAUNCH(false, 1); }
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);

@@ -26,6 +26,23 @@ constexpr int kVFreq = 0, kVW1Last = 64, kVB1 = 64 + kC, kVG1 = 64 + 2 * kC, kVB
               kDimVecs = 64 + 5 * kC;
 constexpr int kVOutG = 0, kVOutBe = kC, kVOutB = 2 * kC, kOutVecs = 3 * kC, kScales = 32;
 
+// sin and cos of an fp32 angle in radians: three-term Cody-Waite reduction by 2 pi (fma, so every step is exact up to the
+// final rounding of the remainder) and the revolution-based hardware v_sin_f32 / v_cos_f32.  Max abs error against the
+// exact sin / cos of the same fp32 angle: 3.7e-7 for |angle| < 6000 (ocml sincosf: 7e-8; scripts/dbg/sincos_acc.hip) at a
+// quarter of its instruction count; angles beyond 2^15 rad take the ocml path.
+__device__ __forceinline__ void sincos_2pi(float ang, float *sn, float *cs)
+{
+    if (__builtin_expect(fabsf(ang) > 32768.0f, 0)) { sincosf(ang, sn, cs); return; }
+    const float inv2pi = 0.15915494309189535f;
+    const float k = rintf(ang * inv2pi);
+    float f = fmaf(-k, 6.28125f, ang);                       // 2 pi = 6.28125 + 1.9350051879882812e-3 + 3.0199159795e-7
+    f = fmaf(-k, 1.9350051879882812e-3f, f);
+    f = fmaf(-k, 3.0199159795074593e-7f, f);
+    const float rev = f * inv2pi;
+    *sn = __builtin_amdgcn_sinf(rev);
+    *cs = __builtin_amdgcn_cosf(rev);
+}
+
 template <int IN, bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__restrict__ x,
                                                              const float *__restrict__ extra, int extra_div,
@@ -66,11 +83,7 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
                 // ((x * f) * 2) * pi in fp32, the reference's evaluation order (:58)
                 const float ang = __fmul_rn(__fmul_rn(__fmul_rn(xv, f4[j]), 2.0f), 3.14159265358979323846f);
                 float sn, cs;
-#ifdef QCN_FAKE_SINCOS
-                sn = ang * 0.001f; cs = ang * 0.002f;
-#else
-                sincosf(ang, &sn, &cs);
-#endif
+                sincos_2pi(ang, &sn, &cs);
                 ft[s >> 4][s & 15] = cs;
                 ft[2 + (s >> 4)][s & 15] = sn;
             }
