@@ -126,6 +126,34 @@ def test_temp_ens_learn_agg_vs_oracle():
     assert torch.allclose(got['pi_softmax'].sum(-1), torch.ones(batch['agent']['num_nodes'], device=DEV), atol=1e-5)
 
 
+def test_ragged_batch_with_dead_agents_vs_oracle():
+    """Ragged inputs: scenarios of different agent / polygon counts in one batch, one agent that is never valid, one
+    that is valid in the history but not predicted, and one scenario with a single polygon — the full ten-frame pass
+    (batched + streaming path) against the CPU oracle, and against the frame-by-frame loop."""
+    from tempenslearnagg_qcnet_amd.data import Batch
+    cfg = config_scene('tiny')
+    model = _model(cfg, seed=3)
+    sd = cpu_state_dict(model)
+    scenes = [make_scenario(0, **cfg['scene']),
+              make_scenario(1, **dict(cfg['scene'], num_agents=9, num_polygons=7)),
+              make_scenario(2, **dict(cfg['scene'], num_agents=3, num_polygons=1)),
+              make_scenario(3, **dict(cfg['scene'], num_agents=4, num_polygons=20))]
+    scenes[1]['agent']['valid_mask'][2] = False                      # never observed
+    scenes[1]['agent']['predict_mask'][2] = False
+    scenes[3]['agent']['predict_mask'][1] = False                    # observed, not predicted (no mode queries updated)
+    batch = Batch.from_data_list(scenes)
+    with torch.no_grad():
+        want = oracle.temp_ens_learn_agg_forward(sd, batch, cfg['hparams'])
+        model = model.to(DEV)
+        got = model.predict(batch.to(DEV))
+        model.batch_frames = False
+        got_loop = model.predict(batch.to(DEV))
+    for k in ('traj_refine', 'pi_softmax', 'final_m', 'loc_refine_pos', 'scale_refine_pos', 'pi'):
+        assert torch.isfinite(got[k]).all(), k
+        assert rel_err(got[k], want[k]) < TOL, k
+        assert rel_err(got[k], got_loop[k]) < 1e-5, k
+
+
 @pytest.mark.parametrize('cfg_name,ids', [('tiny', [0, 1, 2]), ('cfg1', [4])])
 def test_frame_reuse_cache_equals_per_frame_encoding(cfg_name, ids):
     """The absolute-time cache (agent_encoder.precompute) reproduces the per-frame encoder bit for bit, including
