@@ -33,7 +33,7 @@ namespace {
 constexpr int kC = QCN_CHANNELS;       // 128
 
 constexpr int kWaves = 16;
-constexpr int kU = 2;                  // edges per iteration
+constexpr int kSub = 2;                // edges whose positional slices are live at a time
 constexpr float kLog2e = 1.4426950408889634f;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -83,25 +83,26 @@ struct FusedArgs {
     const int32_t *row_index, *src_offset;
 };
 
-struct EdgeRows {
-    float2 k[kU], v[kU], r[kU];
+template <int KU> struct EdgeRows {
+    float2 k[KU], v[KU], r[KU];
 };
 
-template <bool HAS_EID>
-__device__ __forceinline__ void load_indices(const FusedArgs &a, int j, int end, int src_off, int (&src)[kU], int (&e)[kU])
+template <bool HAS_EID, int KU>
+__device__ __forceinline__ void load_indices(const FusedArgs &a, int j, int end, int src_off, int (&src)[KU], int (&e)[KU])
 {
 #pragma unroll
-    for (int t = 0; t < kU; ++t) {
+    for (int t = 0; t < KU; ++t) {
         const int jj = min(j + t, end - 1);           // clamp, masked at the use (no per-load branches)
         src[t] = a.col[jj] + src_off;
         e[t] = HAS_EID ? a.eid[jj] : jj;
     }
 }
 
-__device__ __forceinline__ void load_rows(const FusedArgs &a, const int (&src)[kU], const int (&e)[kU], int lane, EdgeRows &r)
+template <int KU>
+__device__ __forceinline__ void load_rows(const FusedArgs &a, const int (&src)[KU], const int (&e)[KU], int lane, EdgeRows<KU> &r)
 {
 #pragma unroll
-    for (int t = 0; t < kU; ++t) {
+    for (int t = 0; t < KU; ++t) {
         r.k[t] = ld2(a.k, src[t], lane);
         r.v[t] = ld2(a.v, src[t], lane);
         r.r[t] = ld2(a.rhat, e[t], lane);
@@ -115,6 +116,8 @@ template <bool HAS_EID, int R>
 __global__ __launch_bounds__(R == 1 ? 1024 : (R <= 3 ? 512 : 256)) void attn_fused_kernel(FusedArgs a)
 {
     constexpr int kW = R == 1 ? kWaves : (R <= 3 ? kWaves / 2 : kWaves / 4);
+    // edges per iteration = rows requested per prefetch stage (4 with R = 3 spills 48 registers and is 1.6x slower)
+    constexpr int kU = 2;
     // one array (see the chunk swizzle above): [0, 128) rows of wk, [128, 256) rows of wv, then kU staging rows per wave
     __shared__ __attribute__((aligned(16))) float lds[(2 * kC + kW * kU) * kC];
     float *const s_wk = lds, *const s_wv = lds + kC * kC;
@@ -190,10 +193,10 @@ __global__ __launch_bounds__(R == 1 ? 1024 : (R <= 3 ? 512 : 256)) void attn_fus
 
         if (end > beg) {
             int src[kU], e[kU];
-            EdgeRows cur, nxt;
-            load_indices<HAS_EID>(a, beg, end, src_off, src, e);
+            EdgeRows<kU> cur, nxt;
+            load_indices<HAS_EID, kU>(a, beg, end, src_off, src, e);
             load_rows(a, src, e, lane, cur);
-            load_indices<HAS_EID>(a, beg + kU, end, src_off, src, e);
+            load_indices<HAS_EID, kU>(a, beg + kU, end, src_off, src, e);
 
             // ---- prologue: utilde^h[c] = sum_d wk[16h + d][c] * q'^h[d] for the lane's 16-channel slice
             f32x2 u[R][8], s[R][8];   // the slice as channel pairs: packed fp32 FMAs (two channels per instruction)
@@ -228,54 +231,57 @@ __global__ __launch_bounds__(R == 1 ? 1024 : (R <= 3 ? 512 : 256)) void attn_fus
 #pragma unroll
                 for (int t = 0; t < kU; ++t) *reinterpret_cast<float2 *>(s_stage + t * kC + st_off) = cur.r[t];
                 load_rows(a, src, e, lane, nxt);                                    // rows of iteration j + kU
-                load_indices<HAS_EID>(a, j + 2 * kU, end, src_off, src, e);         // indices of iteration j + 2 kU
+                load_indices<HAS_EID, kU>(a, j + 2 * kU, end, src_off, src, e);     // indices of iteration j + 2 kU
                 wave_lds_fence();
-                f32x2 r16[kU][8];
 #pragma unroll
-                for (int t = 0; t < kU; ++t)
+                for (int sb = 0; sb < kU; sb += kSub) {
+                    f32x2 r16[kSub][8];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const f32x4 t4 = *reinterpret_cast<const f32x4 *>(s_stage + t * kC + r_off[i]);
-                        r16[t][2 * i] = f32x2{t4[0], t4[1]};
-                        r16[t][2 * i + 1] = f32x2{t4[2], t4[3]};
-                    }
-                wave_lds_fence();                                  // staging rows are free again
+                    for (int t = 0; t < kSub; ++t)
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    float sim[kU];
-                    float smax = -INFINITY;
-#pragma unroll
-                    for (int t = 0; t < kU; ++t) {
-                        f32x2 pa = f32x2{qv[r].x, qv[r].y} * f32x2{cur.k[t].x, cur.k[t].y}, pb = f32x2{0.f, 0.f};
-#pragma unroll
-                        for (int c = 0; c < 8; c += 2) {
-                            pa = __builtin_elementwise_fma(u[r][c], r16[t][c], pa);
-                            pb = __builtin_elementwise_fma(u[r][c + 1], r16[t][c + 1], pb);
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4 t4 = *reinterpret_cast<const f32x4 *>(s_stage + (sb + t) * kC + r_off[i]);
+                            r16[t][2 * i] = f32x2{t4[0], t4[1]};
+                            r16[t][2 * i + 1] = f32x2{t4[2], t4[3]};
                         }
-                        pa += pb;
-                        const float part = head_sum(pa[0] + pa[1]);
-                        sim[t] = (j + t < end) ? part : -INFINITY;
-                        smax = fmaxf(smax, sim[t]);
-                    }
-                    const float mn = fmaxf(m[r], smax);
-                    if (!__all(mn == m[r])) {                          // running max moved for some head: rescale
-                        const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
-                        l[r] *= alpha; accv[r].x *= alpha; accv[r].y *= alpha;
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) s[r][c] *= alpha;
-                        m[r] = mn;
-                    }
+                    for (int r = 0; r < R; ++r) {
+                        float sim[kSub];
+                        float smax = -INFINITY;
 #pragma unroll
-                    for (int t = 0; t < kU; ++t) {
-                        const float pe = __builtin_amdgcn_exp2f(sim[t] - m[r]);
-                        l[r] += pe;
-                        accv[r].x = fmaf(pe, cur.v[t].x, accv[r].x);
-                        accv[r].y = fmaf(pe, cur.v[t].y, accv[r].y);
-                        const f32x2 pe2 = {pe, pe};
+                        for (int t = 0; t < kSub; ++t) {
+                            f32x2 pa = f32x2{qv[r].x, qv[r].y} * f32x2{cur.k[sb + t].x, cur.k[sb + t].y}, pb = f32x2{0.f, 0.f};
 #pragma unroll
-                        for (int c = 0; c < 8; ++c) s[r][c] = __builtin_elementwise_fma(pe2, r16[t][c], s[r][c]);
+                            for (int c = 0; c < 8; c += 2) {
+                                pa = __builtin_elementwise_fma(u[r][c], r16[t][c], pa);
+                                pb = __builtin_elementwise_fma(u[r][c + 1], r16[t][c + 1], pb);
+                            }
+                            pa += pb;
+                            const float part = head_sum(pa[0] + pa[1]);
+                            sim[t] = (j + sb + t < end) ? part : -INFINITY;
+                            smax = fmaxf(smax, sim[t]);
+                        }
+                        const float mn = fmaxf(m[r], smax);
+                        if (!__all(mn == m[r])) {                      // running max moved for some head: rescale
+                            const float alpha = __builtin_amdgcn_exp2f(m[r] - mn);
+                            l[r] *= alpha; accv[r].x *= alpha; accv[r].y *= alpha;
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) s[r][c] *= alpha;
+                            m[r] = mn;
+                        }
+#pragma unroll
+                        for (int t = 0; t < kSub; ++t) {
+                            const float pe = __builtin_amdgcn_exp2f(sim[t] - m[r]);
+                            l[r] += pe;
+                            accv[r].x = fmaf(pe, cur.v[sb + t].x, accv[r].x);
+                            accv[r].y = fmaf(pe, cur.v[sb + t].y, accv[r].y);
+                            const f32x2 pe2 = {pe, pe};
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) s[r][c] = __builtin_elementwise_fma(pe2, r16[t][c], s[r][c]);
+                        }
                     }
                 }
+                wave_lds_fence();                                  // staging rows are free again
                 cur = nxt;
             }
 
