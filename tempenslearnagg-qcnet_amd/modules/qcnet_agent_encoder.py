@@ -256,10 +256,11 @@ class QCNetAgentEncoder(nn.Module):
         return D
 
     @torch.no_grad()
-    def forward_frames_streaming(self, data, map_enc: Mapping[str, torch.Tensor], cache, needed_from: int) -> torch.Tensor:
-        """``x_a`` [F * A, T, C] of all frames like :meth:`forward_frames`, but only steps >= ``needed_from`` of every
-        frame are produced (the decoder reads the last num_t2m_steps steps, modules/qcnet_decoder.py:143,151; the other
-        entries are left uninitialised), and the work the frames share is done once:
+    def stream_frames(self, data, map_enc: Mapping[str, torch.Tensor], cache, needed_from: int):
+        """The agent encodings of all frames like :meth:`forward_frames`, but only steps >= ``needed_from`` of every
+        frame are produced (the decoder reads the last num_t2m_steps steps, modules/qcnet_decoder.py:143,151), as
+        ``(table [N, C], index [F, A, T - needed_from])`` with ``x_a[f * A + a, needed_from + j] = table[index[f, a, j]]``,
+        and the work the frames share is done once:
 
         * one LONG RUN of the layers over the absolute steps [0, T + F - 1) of all agents (frame 0 is its prefix),
         * per later frame only the few steps of :meth:`streaming_plan` (for the reference configuration one step per
@@ -337,12 +338,29 @@ class QCNetAgentEncoder(nn.Module):
             xl = z[:NA].view(n_abs, A, C).transpose(0, 1)                                                # (a, u) view
             xs = z[NA:].view(F - 1, len(Dl), A, C) if n_own else None
 
-        out = torch.empty(F, A, T, C, dtype=xl.dtype, device=dev)
+        # every needed (frame, agent, step) as a row of ONE table: the long run's rows (a, u) followed by the special rows
+        # of the last layer — consecutive frames share all but one of their steps, so the table has
+        # n_abs + (F - 1) |D| rows per agent where the dense [F, A, T] tensor has F * T
         tail = torch.arange(int(needed_from), T, **i64)
         steps = torch.arange(F, **i64).unsqueeze(1) + tail.unsqueeze(0)                                   # [F, Mt]
-        out[:, :, int(needed_from):] = xl[:, steps].permute(1, 0, 2, 3)
+        index = (a_ids.view(1, A, 1) * n_abs + steps.view(F, 1, -1)).contiguous()                        # [F, A, Mt]
+        parts = [xl.reshape(NA, C)]
         for i, d in enumerate(D[NL]):
-            out[1:, :, d] = xs[:, i]
+            index[1:, :, d - int(needed_from)] = NA + ((frames - 1).view(-1, 1) * len(D[NL]) + i) * A + a_ids.view(1, A)
+        if D[NL]:
+            parts.append(xs.reshape(-1, C))
+        table = torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
+        return table, index
+
+    @torch.no_grad()
+    def forward_frames_streaming(self, data, map_enc: Mapping[str, torch.Tensor], cache, needed_from: int) -> torch.Tensor:
+        """Dense form of :meth:`stream_frames`: ``x_a`` [F * A, T, C] like :meth:`forward_frames`, entries before
+        ``needed_from`` left uninitialised."""
+        T, C = self.num_historical_steps, self.hidden_dim
+        table, index = self.stream_frames(data, map_enc, cache, needed_from)
+        F, A = index.size(0), index.size(1)
+        out = torch.empty(F, A, T, C, dtype=table.dtype, device=table.device)
+        out[:, :, int(needed_from):] = table[index]
         return out.view(F * A, T, C)
 
     def forward(self, data, map_enc: Mapping[str, torch.Tensor], time_shift: int, cache=None,

@@ -138,11 +138,21 @@ class QCNetDecoder(nn.Module):
         head_m = agent['heading'][:, T - 1 + ts].contiguous()
         dev = pos_m.device
 
-        # only the last num_t2m_steps steps are ever sources of the time->mode attention (:143): project those alone
+        # only the last num_t2m_steps steps are ever sources of the time->mode attention (:143): project those alone.
+        # A streamed encoding (QCNetAgentEncoder.stream_frames) comes as a table of distinct rows + an index per
+        # (agent, step): sliding frames share their steps, so the table is several times smaller than [A, Mt].
         Mt = min(self.num_t2m_steps, T)
-        x_t = scene_enc['x_a'][:, T - Mt:].reshape(-1, C)
+        t_index = None
+        if 'x_t_table' in scene_enc:
+            x_t, t_index = scene_enc['x_t_table'], scene_enc['x_t_index']                  # [N, C], [A, Mt] int64
+            if tuple(t_index.shape) != (A, Mt):
+                raise ValueError('x_t_index must be [%d, %d]' % (A, Mt))
+            x_a_now = x_t[t_index[:, -1]]
+        else:
+            x_t = scene_enc['x_a'][:, T - Mt:].reshape(-1, C)
+            x_a_now = scene_enc['x_a'][:, -1]
         x_pl = scene_enc['x_pl'][:, T - 1]          # [P, C]; reference tiles it K times (:150)
-        x_a = scene_enc['x_a'][:, -1]               # [A, C]; reference tiles it K times (:151)
+        x_a = x_a_now                               # [A, C]; reference tiles it K times (:151)
         m = self.mode_emb.weight.repeat(A, 1)
 
         mask_src = agent['valid_mask'][:, ts:T + ts].clone()
@@ -159,8 +169,10 @@ class QCNetDecoder(nn.Module):
         ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
         g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
         col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
-        g_t2m = g_t2m.remap_sources(col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt), A * Mt).replicate(
-            K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
+        col = col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt)
+        if t_index is not None:
+            col = t_index.reshape(-1)[col]
+        g_t2m = g_t2m.remap_sources(col, x_t.size(0)).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
 
         pos_pl = data['map_polygon']['position'][:, :2].contiguous()
         orient_pl = data['map_polygon']['orientation'].contiguous()

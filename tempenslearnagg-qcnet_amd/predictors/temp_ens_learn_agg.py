@@ -69,16 +69,20 @@ class TempEnsLearnAgg(nn.Module):
         A = int(data['agent']['num_nodes'])
         map_enc = enc.map_encoder(data)
         cache = enc.agent_encoder.precompute(data, 1, n_f)
-        if self.stream_encoder:
-            x_a = enc.agent_encoder.forward_frames_streaming(data, map_enc, cache, T - min(dec.num_t2m_steps, T))
-        else:
-            x_a = enc.agent_encoder.forward_frames(data, map_enc, cache)                   # [F * A, T, C]
-        frames = frame_batch(data, 1, n_f, T + 2)
         x_pl = map_enc['x_pl'][:, 0]
-        scene = {'x_a': x_a, 'x_pl': x_pl.repeat(n_f, 1).unsqueeze(1).expand(-1, T, -1)}
+        x_pl_frames = x_pl.repeat(n_f, 1).unsqueeze(1).expand(-1, T, -1)
+        frames = frame_batch(data, 1, n_f, T + 2)
+        if self.stream_encoder:
+            Mt = min(dec.num_t2m_steps, T)
+            table, index = enc.agent_encoder.stream_frames(data, map_enc, cache, T - Mt)           # [N, C], [F, A, Mt]
+            scene = {'x_t_table': table, 'x_t_index': index.view(n_f * A, Mt), 'x_pl': x_pl_frames}
+            scene_last = {'x_t_table': table, 'x_t_index': index[n_f - 1], 'x_pl': map_enc['x_pl']}
+        else:
+            x_a = enc.agent_encoder.forward_frames(data, map_enc, cache)                           # [F * A, T, C]
+            scene = {'x_a': x_a, 'x_pl': x_pl_frames}
+            scene_last = {'x_a': x_a[(n_f - 1) * A:], 'x_pl': map_enc['x_pl']}
         pred = dec(frames, scene, 1)
         temporal_m = pred['m'].view(n_f, A, self.num_modes, self.hidden_dim).transpose(0, 1)
-        scene_last = {'x_a': x_a[(n_f - 1) * A:], 'x_pl': map_enc['x_pl']}
         return self._finish(self.temporal_aggregate_layer(temporal_m, data, scene_last, n_f))
 
     @torch.no_grad()
