@@ -166,6 +166,13 @@ size_t qcn_fourier_pack_floats(int input_dim);
 int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
                           const float *pack, int64_t n_rows, int normalize_out, float *y, void *stream);
 
+/* A4 followed by up to three Linear(128,128) layers on the embedding before it leaves the registers:
+ * y_j = W_j FourierEmbedding(x) + b_j, j < n_out <= 3 (the decoder's trajectory re-encoding, modules/qcnet_decoder.py:255-257:
+ * y_emb followed by the GRU's input half W_i* y + b_i*).  wt / bias as for qcn_ln_linear_f32; the embedding is not stored. */
+int qcn_fourier_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
+                           const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
+                           float *y0, float *y1, float *y2, void *stream);
+
 /* A2 node side (K5/K6 of SURVEY.md §2b fused) — xn = LayerNorm(x) (skipped when ln_weight == NULL);
  * y_j = W_j xn + b_j for j < n_out <= 4 (the to_q / to_k / to_v / to_s projections of one AttentionLayer call,
  * layers/attention_layer.py:74-79,115-117,108).  x, y_j, xn_out: [n_rows,128]; wt: n_out chain-packed matrices

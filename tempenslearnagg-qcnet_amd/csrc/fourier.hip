@@ -43,11 +43,19 @@ __device__ __forceinline__ void sincos_2pi(float ang, float *sn, float *cs)
     *cs = __builtin_amdgcn_cosf(rev);
 }
 
+// Optional linear layers applied to the embedding before it leaves the registers (qcn_fourier_linear_f32): y_j = W_j emb + b_j.
+struct FourierTail {
+    const float *wt;      // n_out chain-packed matrices + their scale pairs (the qcn_ln_linear_f32 layout)
+    const float *bias;    // [n_out, 128] or nullptr
+    float *y[3];
+    int n_out;            // 0: store the embedding itself
+};
+
 template <int IN, bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__restrict__ x,
                                                              const float *__restrict__ extra, int extra_div,
                                                              const float *__restrict__ pack, float *__restrict__ y,
-                                                             int64_t n_rows, int normalize_out)
+                                                             int64_t n_rows, int normalize_out, FourierTail tail)
 {
     __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
@@ -130,9 +138,25 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     load_feature_vec(acc_o, out_vec + kVOutB, h);
     make_operand(op, acc_y);
     sync_for_stage();
-    gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane);
+    gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
     if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
-    if (valid) store_row(acc_o, y, row, h);
+    if (tail.n_out == 0) {
+        if (valid) store_row(acc_o, y, row, h);
+        return;
+    }
+    // ---- tail: the embedding is the operand of n_out more layers (matrix j sits in buffer (j + 1) & 1)
+    make_operand(op, acc_o);
+    const float *tsc = tail.wt + (size_t)tail.n_out * kMatFloats;
+#pragma unroll 1
+    for (int j = 0; j < tail.n_out; ++j) {
+        f32x16 acc[4];
+        if (tail.bias != nullptr) load_feature_vec(acc, tail.bias + j * kC, h);
+        else fill_zero(acc);
+        sync_for_stage();
+        gemm<WAVES>(acc, op, wlds + ((j + 1) & 1) * kMatVec4, tsc + 2 * j, lane,
+                    j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr, wlds + (j & 1) * kMatVec4, wave);
+        if (valid) store_row(acc, tail.y[j], row, h);
+    }
 }
 
 }  // namespace
@@ -142,22 +166,22 @@ extern "C" size_t qcn_fourier_pack_floats(int input_dim)
     return (size_t)(2 * input_dim + 1) * kMatFloats + (size_t)input_dim * kDimVecs + kOutVecs + kScales;
 }
 
-extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
-                                     const float *pack, int64_t n_rows, int normalize_out, float *y, void *stream)
+static int launch_fourier(const float *x, int input_dim, const float *extra, int64_t extra_div, const float *pack,
+                          int64_t n_rows, int normalize_out, float *y, const FourierTail &tail, void *stream)
 {
     if (n_rows < 0 || input_dim < 0 || input_dim > 4) return n_rows < 0 ? QCN_ERR_INVALID_ARGUMENT : QCN_ERR_UNSUPPORTED;
     if (n_rows == 0) return QCN_OK;
-    if (!pack || !y || (input_dim > 0 && !x) || (input_dim == 0 && !extra)) return QCN_ERR_INVALID_ARGUMENT;
+    if (!pack || (tail.n_out == 0 && !y) || (input_dim > 0 && !x) || (input_dim == 0 && !extra)) return QCN_ERR_INVALID_ARGUMENT;
     if (extra_div < 1 || extra_div > 0x7fffffff) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
     const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
     const int waves = pick_waves(n_rows, split);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
-    const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC);
+    const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC * (1 + tail.n_out));
     void *token = qcn_prof_begin(QCN_PROF_FOURIER, flops, s);
 #define QCN_LAUNCH(S, W)                                                                                           \
     hipLaunchKernelGGL((fourier_kernel<QCN_IN, S, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, \
-                       n_rows, normalize_out)
+                       n_rows, normalize_out, tail)
     switch (input_dim) {
 #define QCN_IN 0
     case 0: QCN_CHAIN_DISPATCH(split, waves); break;
@@ -179,4 +203,20 @@ extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float 
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
+}
+
+extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
+                                     const float *pack, int64_t n_rows, int normalize_out, float *y, void *stream)
+{
+    FourierTail tail{};
+    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, normalize_out, y, tail, stream);
+}
+
+extern "C" int qcn_fourier_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
+                                      const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
+                                      float *y0, float *y1, float *y2, void *stream)
+{
+    if (n_out < 1 || n_out > 3 || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
+    FourierTail tail{wt, bias, {y0, y1, y2}, n_out};
+    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, stream);
 }

@@ -212,8 +212,10 @@ class QCNetDecoder(nn.Module):
 
         # trajectory re-encoding: Fourier embedding of the proposed way-points, GRU over the Tf steps, last hidden state
         # (reference :255-257); row n * Tf + t of the embedding is step t of mode query n
-        m = self.y_emb(loc_propose_pos.detach().reshape(-1, OD))
-        m = ops.gru_last_hidden(m, Tf, *self._gru_packs())
+        wih_t, b_ih, whh, b_hh, h0 = self._gru_packs()
+        gi = ops.fourier_linear(loc_propose_pos.detach().reshape(-1, OD).contiguous().float(), OD,
+                                self.y_emb.packed_weights(), wih_t, b_ih)      # y_emb + the GRU's input half, one launch
+        m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0)
         m = self._fuse_modes(m, temporal_m)
         m = self._cross_stack('refine', m, *graphs)
 

@@ -256,6 +256,25 @@ def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor,
     return y
 
 
+def fourier_linear(x: torch.Tensor, input_dim: int, pack: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor]):
+    """qcn_fourier_linear_f32: [W_j FourierEmbedding(x) + b_j] for the n_out <= 3 layers of ``wt`` (pack_chain_matrices)."""
+    dev = pack.device
+    _require(x, 'continuous_inputs', torch.float32, dev, (None, input_dim))
+    n = x.size(0)
+    _require(pack, 'pack', torch.float32, dev, (int(_lib.lib().qcn_fourier_pack_floats(int(input_dim))),))
+    n_out = wt.numel() // (C * C + 2)
+    if not 1 <= n_out <= 3:
+        raise ValueError('n_out must be 1..3')
+    _require(wt, 'wt', torch.float32, dev, (n_out * (C * C + 2),))
+    if bias is not None:
+        _require(bias, 'bias', torch.float32, dev, (n_out, C))
+    ys = [torch.empty(n, C, dtype=torch.float32, device=dev) for _ in range(n_out)]
+    yp = [_ptr(y) for y in ys] + [None] * (3 - n_out)
+    _lib.check(_lib.lib().qcn_fourier_linear_f32(_ptr(x), int(input_dim), None, 1, _ptr(pack), n, _ptr(wt), _ptr(bias), n_out,
+                                                 yp[0], yp[1], yp[2], _stream(dev)), 'qcn_fourier_linear_f32')
+    return ys
+
+
 def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], wt: torch.Tensor,
               bias: Optional[torch.Tensor], want_xn: bool = False):
     """qcn_ln_linear_f32: ([y_0 .. y_{n_out-1}], xn or None) with y_j = W_j LayerNorm(x) + b_j; ``wt`` is the stack
@@ -398,14 +417,25 @@ def gru_last_hidden(x_seq: torch.Tensor, n_steps: int, wih_t: torch.Tensor, b_ih
     _require(x_seq, 'x_seq', torch.float32, dev, (None, C))
     if x_seq.size(0) % n_steps:
         raise ValueError('x_seq rows (%d) not a multiple of n_steps (%d)' % (x_seq.size(0), n_steps))
-    n_seq = x_seq.size(0) // n_steps
+    (gi_r, gi_z, gi_n), _ = ln_linear(x_seq, None, None, wih_t, b_ih)
+    return gru_recurrence(gi_r, gi_z, gi_n, n_steps, whh_t, b_hh, h0)
+
+
+def gru_recurrence(gi_r: torch.Tensor, gi_z: torch.Tensor, gi_n: torch.Tensor, n_steps: int, whh_t: torch.Tensor,
+                   b_hh: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
+    """qcn_gru_f32 on precomputed input halves gi_* [n_seq * n_steps, 128]."""
+    dev = gi_r.device
+    if n_steps < 1 or gi_r.size(0) % n_steps:
+        raise ValueError('gi rows (%d) not a multiple of n_steps (%d)' % (gi_r.size(0), n_steps))
+    n_seq = gi_r.size(0) // n_steps
     if matmul_mode() == MATMUL_EXACT_F32:
         _require(whh_t, 'whh_t', torch.float32, dev, (C, 3 * C))
     else:
         _require(whh_t, 'whh_t', torch.float32, dev, (int(_lib.lib().qcn_gru_pack_floats()),))
     _require(b_hh, 'b_hh', torch.float32, dev, (3 * C,))
     _require(h0, 'h0', torch.float32, dev, (C,))
-    (gi_r, gi_z, gi_n), _ = ln_linear(x_seq, None, None, wih_t, b_ih)
+    for name, t in (('gi_r', gi_r), ('gi_z', gi_z), ('gi_n', gi_n)):
+        _require(t, name, torch.float32, dev, (n_seq * n_steps, C))
     h = torch.empty(n_seq, C, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_gru_f32(_ptr(gi_r), _ptr(gi_z), _ptr(gi_n), _ptr(whh_t), _ptr(b_hh), _ptr(h0), n_seq,
                                       int(n_steps), _ptr(h), _stream(dev)), 'qcn_gru_f32')
