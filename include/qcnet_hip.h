@@ -189,7 +189,9 @@ int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, co
  *   [to_g.weight[:, :128], to_g.weight[:, 128:], to_out.weight, then for hb = 0..3:
  *    ff_mlp.0.weight[128hb:128hb+128, :], ff_mlp.3.weight[:, 128hb:128hb+128]]
  * followed by [to_g.bias, to_out.bias, attn_postnorm.{weight,bias}, ff_prenorm.{weight,bias}, ff_mlp.0.bias (512),
- *   ff_mlp.3.bias, ff_postnorm.{weight,bias}], then the scale table (32 floats, {scale, 1 / scale} per matrix).  All tensors [n_rows,128] fp32; out must not alias an input (it parks
+ *   ff_mlp.3.bias, ff_postnorm.{weight,bias}, attn_prenorm_x_dst.{weight,bias}], then the scale table (32 floats, {scale, 1 / scale} per matrix).  xn_dst = attn_prenorm_x_dst(x_res) as
+ * written by qcn_ln_linear_f32, or NULL: it is then recomputed from x_res (same arithmetic, no round trip).
+ * All tensors [n_rows,128] fp32; out must not alias an input (it parks
  * x1 between the two residuals). */
 size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,

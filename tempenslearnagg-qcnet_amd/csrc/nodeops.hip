@@ -57,11 +57,12 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
 }
 
 // pack: 11 chain-packed matrices in consumption order [Wg_agg, Wg_x, Wout, W1_0, W2_0, W1_1, W2_1, W1_2, W2_2, W1_3, W2_3]
-// then plain vectors [bg, bout, lnpost_g, lnpost_b, lnffpre_g, lnffpre_b, b1 (512), b2, lnffpost_g, lnffpost_b]
-// then {scale, 1 / scale} per matrix (32 floats reserved)
+// then plain vectors [bg, bout, lnpost_g, lnpost_b, lnffpre_g, lnffpre_b, b1 (512), b2, lnffpost_g, lnffpost_b,
+// lnpre_dst_g, lnpre_dst_b] then {scale, 1 / scale} per matrix (32 floats reserved)
 constexpr int kPostMats = 11;
 constexpr int kVBg = 0, kVBout = kC, kVLpG = 2 * kC, kVLpB = 3 * kC, kVLfG = 4 * kC, kVLfB = 5 * kC, kVB1 = 6 * kC,
-              kVB2 = 10 * kC, kVLqG = 11 * kC, kVLqB = 12 * kC, kPostVecs = 13 * kC, kPostScales = 32;
+              kVB2 = 10 * kC, kVLqG = 11 * kC, kVLqB = 12 * kC, kVPreG = 13 * kC, kVPreB = 14 * kC,
+              kPostVecs = 15 * kC, kPostScales = 32;
 
 template <bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__restrict__ agg,
@@ -94,7 +95,12 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     gemm<WAVES>(acc, op, buf0, msc + 0, lane, mats + kMatFloats, buf1, wave);
     {
         f32x16 vx[4];
-        load_row(vx, xn, rowc, h);
+        if (xn != nullptr) {
+            load_row(vx, xn, rowc, h);
+        } else {   // xn = attn_prenorm_x_dst(x): recomputed (same arithmetic as qcn_ln_linear_f32) instead of a round trip
+            load_row(vx, xres, rowc, h);
+            layer_norm<true, false>(vx, vec + kVPreG, vec + kVPreB, h, eps);
+        }
         make_operand(op, vx);
         sync_for_stage();
         gemm<WAVES>(acc, op, buf1, msc + 2, lane, mats + 2 * kMatFloats, buf0, wave);
@@ -287,7 +293,7 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
 {
     if (n_rows < 0) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows == 0) return QCN_OK;
-    if (!agg || !xn_dst || !s_proj || !x_res || !pack || !out) return QCN_ERR_INVALID_ARGUMENT;
+    if (!agg || !s_proj || !x_res || !pack || !out) return QCN_ERR_INVALID_ARGUMENT;   // xn_dst may be NULL
     if (out == agg || out == xn_dst || out == s_proj || out == x_res) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
     const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;

@@ -107,7 +107,7 @@ class AttentionLayer(nn.Module):
             mats = [mats]
             vecs = [self.to_g.bias, self.to_out.bias, self.attn_postnorm.weight, self.attn_postnorm.bias,
                     self.ff_prenorm.weight, self.ff_prenorm.bias, w1.bias, w2.bias, self.ff_postnorm.weight,
-                    self.ff_postnorm.bias]
+                    self.ff_postnorm.bias, self.attn_prenorm_x_dst.weight, self.attn_prenorm_x_dst.bias]
             packs['post'] = torch.cat([m.reshape(-1) for m in mats] + [v.reshape(-1).float() for v in vecs]
                                       + [ops.scale_table(scales)]).contiguous()
             if self.has_pos_emb:
@@ -153,10 +153,10 @@ class AttentionLayer(nn.Module):
         if not single:
             ln_s, ln_d = self.attn_prenorm_x_src, self.attn_prenorm_x_dst
             (k, v), _ = ops.ln_linear(x_src, ln_s.weight, ln_s.bias, *packs['pre_src'])
-            (q, s), xn_dst = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'], want_xn=True)
+            (q, s), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'])
         else:
             ln = self.attn_prenorm_x_src
-            (q, k, v, s), xn_dst = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_all'], want_xn=True)
+            (q, k, v, s), _ = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_all'])
         # propagate: gather + segment softmax + weighted scatter-add (one launch)
         if r is not None:
             wk, wv, bv = packs['pos']
@@ -167,4 +167,5 @@ class AttentionLayer(nn.Module):
                 raise ValueError('mode-replicated / windowed graphs need a positional embedding')
             agg = ops.attn_fwd(q, k, v, None, None, graph.rowptr, graph.col, graph.eid)
         # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)
-        return ops.attn_post(agg, xn_dst, s, x_res, packs['post'])
+        # the gate's LN(x_dst) is recomputed inside the kernel (xn_dst = None): cheaper than a [N, 128] round trip
+        return ops.attn_post(agg, None, s, x_res, packs['post'])

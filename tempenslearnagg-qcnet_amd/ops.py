@@ -300,12 +300,15 @@ def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optio
     return ys, xn
 
 
-def attn_post(agg: torch.Tensor, xn_dst: torch.Tensor, s_proj: torch.Tensor, x_res: torch.Tensor,
+def attn_post(agg: torch.Tensor, xn_dst: Optional[torch.Tensor], s_proj: torch.Tensor, x_res: torch.Tensor,
               pack: torch.Tensor) -> torch.Tensor:
-    """qcn_attn_post_f32: gate/update + to_out + post-norm residual + feed-forward block of one AttentionLayer."""
+    """qcn_attn_post_f32: gate/update + to_out + post-norm residual + feed-forward block of one AttentionLayer.
+    ``xn_dst`` None: the kernel recomputes attn_prenorm_x_dst(x_res) from the affine stored in ``pack``."""
     dev = agg.device
     n = agg.size(0)
     for name, t in (('agg', agg), ('xn_dst', xn_dst), ('s_proj', s_proj), ('x_res', x_res)):
+        if t is None and name == 'xn_dst':
+            continue
         _require(t, name, torch.float32, dev, (n, C))
     _require(pack, 'pack', torch.float32, dev, (_lib.lib().qcn_attn_post_pack_floats(),))
     out = torch.empty(n, C, dtype=torch.float32, device=dev)
