@@ -117,13 +117,14 @@ class QCNetDecoder(nn.Module):
         t2m = getattr(self, 't2m_%s_attn_layers' % stage)
         pl2m = getattr(self, 'pl2m_%s_attn_layers' % stage)
         a2m = getattr(self, 'a2m_%s_attn_layers' % stage)
+        # The reference flips the mode queries between agent-major (t2m, m2m) and mode-major (pl2m, a2m) node order
+        # (:223,226).  The kernel takes the node order of a mode-replicated relation as a parameter, so m stays
+        # agent-major throughout and the four transposes per layer pair disappear.
+        m = m.reshape(-1, C)
         for i in range(self.num_layers):
-            m = m.reshape(-1, C)
             m = t2m[i]((x_t, m), r_t2m, g_t2m)
-            m = m.reshape(-1, K, C).transpose(0, 1).reshape(-1, C)          # agent-major -> mode-major
             m = pl2m[i]((x_pl, m), r_pl2m, g_pl2m)
             m = a2m[i]((x_a, m), r_a2m, g_a2m)
-            m = m.reshape(K, -1, C).transpose(0, 1).reshape(-1, C)          # back to agent-major
         m = getattr(self, 'm2m_%s_attn_layer' % stage)(m, None, g_m2m)
         return m.reshape(-1, K, C)
 
@@ -183,7 +184,7 @@ class QCNetDecoder(nn.Module):
             continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=True))
         ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
         g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False).replicate(
-            K, ops.LAYOUT_MODE_MAJOR, edge_index=ei_pl2m)
+            K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_pl2m)
 
         src_ok = mask_src[:, -1].contiguous()
         ei_a2m_1, off_a2m = ops.radius_pairs(pos_m, pos_m, self.a2m_radius, ptr_a, ptr_a, 300 + 1, drop_self=True,
@@ -191,7 +192,7 @@ class QCNetDecoder(nn.Module):
         r_a2m = NormalizedEdgeFeatures(self.r_a2m_emb(
             continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None, normalized_output=True))
         ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
-        g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_MODE_MAJOR, edge_index=ei_a2m)
+        g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_a2m)
 
         ei_m2m = dense_to_sparse(mask_dst.unsqueeze(2) & mask_dst.unsqueeze(1))[0]
         g_m2m = CSRGraph.from_edge_index(ei_m2m, A * K, A * K, validate=False)
