@@ -279,23 +279,25 @@ class QCNetAgentEncoder(nn.Module):
         a_ids = torch.arange(A, **i64)
         frames = torch.arange(1, F, **i64)                                            # frames with special steps
 
-        xl = torch.cat([cache['x_first'][:, :1], cache['x_main'][:, 1:]], dim=1)      # [A, n_abs, C], (a, u) order
+        # long-run rows in time-major order (row u * A + a) through all layers: the spatial relations are time-major
+        # anyway and the temporal edge list is simply numbered the same way, so nothing is ever transposed
+        xl = torch.cat([cache['x_first'][:, :1], cache['x_main'][:, 1:]], dim=1).transpose(0, 1).reshape(NA, C)
         xs = cache['x_first'][:, 1:].transpose(0, 1).unsqueeze(1) if D[0] else None   # [F-1, |D0|, A, C]
         t_src, t_dst, t_agent = cache['t_src'], cache['t_dst'], cache['t_agent']
         E_abs = t_src.numel()
-        can_src, can_dst = t_agent * n_abs + t_src, t_agent * n_abs + t_dst
+        can_src, can_dst = t_src * A + t_agent, t_dst * A + t_agent
         for l in range(1, NL + 1):
             Dp, Dl = D[l - 1], D[l]
             n_prev, n_own = (F - 1) * len(Dp) * A, (F - 1) * len(Dl) * A
-            parts = [xl.reshape(NA, C)]
+            # input rows: [long run | the special destinations' own rows | special source rows of the previous layer];
+            # the first NA + n_own output rows are the ones that go on
+            parts = [xl]
             src_all, dst_all, eid_all = [can_src], [can_dst], [torch.arange(E_abs, **i64)]
-            if n_prev:
-                parts.append(xs.reshape(n_prev, C))
             if n_own:
                 # the destinations' own rows (residual / query input): previous-layer value at (f, d)
                 own = []
                 for d in Dl:
-                    own.append(xs[:, Dp.index(d)] if d in Dp else xl[:, frames + d].transpose(0, 1))   # [F-1, A, C]
+                    own.append(xs[:, Dp.index(d)] if d in Dp else xl.view(n_abs, A, C)[frames + d])      # [F-1, A, C]
                 parts.append(torch.stack(own, dim=1).reshape(n_own, C))
                 # their temporal edges: absolute edges into step f + d whose source lies inside frame f
                 d_vec = torch.tensor(Dl, **i64)
@@ -310,47 +312,44 @@ class QCNetAgentEncoder(nn.Module):
                     pos_in_prev[torch.tensor(Dp, **i64)] = torch.arange(len(Dp), **i64)
                 slot = pos_in_prev[dp.clamp(0, T)]
                 is_special = dp <= (l - 1) * S
-                src_special = NA + ((fj - 1) * max(len(Dp), 1) + slot.clamp_min(0)) * A + ag
-                src_all.append(torch.where(is_special, src_special, ag * n_abs + t_src[e_sel]))
-                dst_all.append(NA + n_prev + j_sel * A + ag)
+                src_special = NA + n_own + ((fj - 1) * max(len(Dp), 1) + slot.clamp_min(0)) * A + ag
+                src_all.append(torch.where(is_special, src_special, t_src[e_sel] * A + ag))
+                dst_all.append(NA + j_sel * A + ag)
                 eid_all.append(e_sel)
-            n_all = NA + n_prev + n_own
-            g_t = CSRGraph.from_edge_index(torch.stack([torch.cat(src_all), torch.cat(dst_all)]), n_all, n_all,
+                if n_prev:
+                    parts.append(xs.reshape(n_prev, C))
+            n_in = NA + n_own + (n_prev if n_own else 0)
+            g_t = CSRGraph.from_edge_index(torch.stack([torch.cat(src_all), torch.cat(dst_all)]), n_in, n_in,
                                            validate=False)
             g_t.eid = torch.cat(eid_all).to(torch.int32)[g_t.eid.long()]
             g_t.num_feature_rows = cache['r_t'].rhat.size(0)
             y = self.t_attn_layers[l - 1](torch.cat(parts) if len(parts) > 1 else parts[0], cache['r_t'], g_t)
 
-            # spatial relations: time-major long-run rows, then the special rows (f, d, a)
-            yc = y[:NA].view(A, n_abs, C).transpose(0, 1).reshape(NA, C)
+            # spatial relations over [long run | special rows (f, d, a)]
+            x2 = y[:NA + n_own]
             if n_own:
                 u_rows = ((frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1, 1) * A + a_ids.unsqueeze(0)).reshape(-1)
                 row_index = torch.cat([torch.arange(NA, **i64), u_rows])
                 blk = NA + torch.arange(n_own, **i64)
                 src_offset = torch.cat([torch.zeros(NA, **i64), blk - blk % A - (u_rows - u_rows % A)])
-                x2 = torch.cat([yc, y[NA + n_prev:]])
                 g_pl2a = cache['g_pl2a'].with_rows(row_index, None, P)
                 g_a2a = cache['g_a2a'].with_rows(row_index, src_offset, NA + n_own)
             else:
-                x2, g_pl2a, g_a2a = yc, cache['g_pl2a'], cache['g_a2a']
+                g_pl2a, g_a2a = cache['g_pl2a'], cache['g_a2a']
             z = self.pl2a_attn_layers[l - 1]((x_pl, x2), cache['r_pl2a'], g_pl2a)
             z = self.a2a_attn_layers[l - 1](z, cache['r_a2a'], g_a2a)
-            xl = z[:NA].view(n_abs, A, C).transpose(0, 1)                                                # (a, u) view
+            xl = z[:NA]
             xs = z[NA:].view(F - 1, len(Dl), A, C) if n_own else None
 
-        # every needed (frame, agent, step) as a row of ONE table: the long run's rows (a, u) followed by the special rows
+        # every needed (frame, agent, step) as a row of ONE table: the long run's rows (u, a) followed by the special rows
         # of the last layer — consecutive frames share all but one of their steps, so the table has
-        # n_abs + (F - 1) |D| rows per agent where the dense [F, A, T] tensor has F * T
+        # n_abs + (F - 1) |D| rows per agent (time-major) where the dense [F, A, T] tensor has F * T
         tail = torch.arange(int(needed_from), T, **i64)
         steps = torch.arange(F, **i64).unsqueeze(1) + tail.unsqueeze(0)                                   # [F, Mt]
-        index = (a_ids.view(1, A, 1) * n_abs + steps.view(F, 1, -1)).contiguous()                        # [F, A, Mt]
-        parts = [xl.reshape(NA, C)]
+        index = (steps.view(F, 1, -1) * A + a_ids.view(1, A, 1)).contiguous()                            # [F, A, Mt]
         for i, d in enumerate(D[NL]):
             index[1:, :, d - int(needed_from)] = NA + ((frames - 1).view(-1, 1) * len(D[NL]) + i) * A + a_ids.view(1, A)
-        if D[NL]:
-            parts.append(xs.reshape(-1, C))
-        table = torch.cat(parts) if len(parts) > 1 else parts[0].contiguous()
-        return table, index
+        return z, index          # the last layer's output already is [long run | special rows]
 
     @torch.no_grad()
     def forward_frames_streaming(self, data, map_enc: Mapping[str, torch.Tensor], cache, needed_from: int) -> torch.Tensor:
