@@ -124,6 +124,25 @@ int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const flo
                        int64_t num_edges, int rep, int layout, int64_t col_shift, const int32_t *row_index,
                        const int32_t *src_offset, float *out, void *stream);
 
+/* A3 for mode-replicated relations, on the matrix cores — same result as qcn_attn_fused_f32 with layout 1 or 2 and
+ * rep <= 6 (the decoder's t2m / pl2m / a2m relations, modules/qcnet_decoder.py:190-226,259-263 with num_modes = 6):
+ * per (CSR row, edge) the projected key / value  k[j] + to_k_r(LN_r(r_e)),  v[j] + to_v_r(LN_r(r_e))  are computed once
+ * as split-f16 MFMA products and shared by the rep mode queries of the row (csrc/attention_modes.hip).
+ *   rhat_split [E_base rows, 256] f16: row e = [hi (128) | lo (128)] with hi + lo = rhat_e * 2^11, made by
+ *     qcn_split_rows_f16(rhat, n, 11, out)  (rhat = qcn_row_normalize_f32 output / a normalising qcn_fourier_embed_f32);
+ *   wpack: qcn_attn_modes_pack_bytes() bytes = [head 8][wk | wv][k-step 4][hi | lo][lane 64][8 f16] with
+ *     frag[lane][j] = W[16 head + (lane & 15)][32 kstep + 8 (lane >> 4) + j] * 2^sw  (wk, wv as in qcn_attn_fused_f32,
+ *     sw = the power of two that puts max |W| into [2^14, 2^15)), then two fp32: 2^-(sw_k + 11), 2^-(sw_v + 11)
+ *     (host: ops.pack_attn_modes);
+ *   the other arguments as in qcn_attn_fused_f32 (no row_index / src_offset).
+ * Logits and the weighted sums are exact-fp32 MFMAs; |k + to_k_r(.)| is not limited. */
+int qcn_split_rows_f16(const float *x, int64_t n_rows, int scale_log2, void *y, void *stream);
+size_t qcn_attn_modes_pack_bytes(void);
+int qcn_attn_modes_f32(const float *q, const float *k, const float *v, const void *rhat_split,
+                       const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                       const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                       int rep, int layout, int64_t col_shift, float *out, void *stream);
+
 /* Arithmetic of the three MFMA chain kernels below (qcn_fourier_embed_f32, qcn_ln_linear_f32, qcn_attn_post_f32).
  *   QCN_MATMUL_EXACT_F32: v_mfma_f32_32x32x2_f32, exact fp32 fma chains.
  *   QCN_MATMUL_SPLIT_F16 (default): every fp32 operand carried as hi + lo of two f16 numbers (22 significant bits)

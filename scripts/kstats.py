@@ -1,5 +1,5 @@
 import csv, sys, glob
-f = glob.glob(sys.argv[1] + '/*/*kernel_stats.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*kernel_stats.csv') + glob.glob(sys.argv[1] + '/*kernel_stats.csv'))[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r['TotalDurationNs']) for r in rows)
 print('total kernel ms', tot/1e6, 'n kernels', len(rows))

@@ -6,6 +6,7 @@ gather → segment softmax → scatter-add of ``propagate`` is one HIP kernel ov
 (``qcn_attn_fwd_f32``).  Inference only — dropout sites (:49,53,99) are identities in eval mode and the layer
 refuses to run in training mode with ``dropout > 0``.
 """
+import os
 from typing import Optional, Tuple, Union
 
 import torch
@@ -16,16 +17,29 @@ from ..utils.graph import CSRGraph
 from ..utils.weight_init import weight_init
 
 
+# QCN_ATTN_MODES=0 routes mode-replicated relations through qcn_attn_fused_f32 instead of qcn_attn_modes_f32 (A/B runs)
+USE_ATTN_MODES = os.environ.get('QCN_ATTN_MODES', '1') != '0'
+
+
 class NormalizedEdgeFeatures:
     """Positional embeddings of a relation after the layer-independent half of ``attn_prenorm_r``:
     ``rhat = (r - mean) / sqrt(var + eps)`` per edge, [E_base, 128].  Every AttentionLayer that consumes the
     relation applies only its own affine (folded into its projection weights), so the normalisation is done
     once per relation instead of once per layer (reference: layers/attention_layer.py:82 in every call)."""
 
-    __slots__ = ('rhat',)
+    __slots__ = ('rhat', '_split')
 
     def __init__(self, rhat: torch.Tensor) -> None:
         self.rhat = rhat
+        self._split = None
+
+    @property
+    def split(self) -> torch.Tensor:
+        """The same rows as split f16 ([E_base, 256], qcn_split_rows_f16): the operand format of qcn_attn_modes_f32,
+        converted once per relation on first use."""
+        if self._split is None:
+            self._split = ops.split_rows(self.rhat)
+        return self._split
 
     @classmethod
     def from_raw(cls, r: torch.Tensor, eps: float = 1e-5) -> 'NormalizedEdgeFeatures':
@@ -115,6 +129,7 @@ class AttentionLayer(nn.Module):
                 packs['pos'] = ((self.to_k_r.weight * gamma.unsqueeze(0)).contiguous(),
                                 (self.to_v_r.weight * gamma.unsqueeze(0)).contiguous(),
                                 (self.to_v_r.weight @ beta + self.to_v_r.bias).contiguous())
+                packs['pos_modes'] = ops.pack_attn_modes(packs['pos'][0], packs['pos'][1])
         self._packs, self._pack_key = packs, key
         return packs
 
@@ -160,8 +175,14 @@ class AttentionLayer(nn.Module):
         # propagate: gather + segment softmax + weighted scatter-add (one launch)
         if r is not None:
             wk, wv, bv = packs['pos']
-            agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep, graph.layout,
-                                 graph.col_shift, graph.row_index, graph.src_offset)
+            if 1 < graph.rep <= 6 and graph.layout != ops.LAYOUT_PLAIN and USE_ATTN_MODES:
+                # mode-replicated relation: per-edge projections once per (row, edge) on the matrix cores
+                agg = ops.attn_modes(q, k, v, r.split, graph.rowptr, graph.col, graph.eid, packs['pos_modes'], bv,
+                                     graph.rep, graph.layout, graph.col_shift)
+            else:
+                agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep,
+                                     graph.layout,
+                                     graph.col_shift, graph.row_index, graph.src_offset)
         else:
             if graph.rep != 1 or graph.col_shift != 0 or graph.row_index is not None or graph.src_offset is not None:
                 raise ValueError('mode-replicated / windowed graphs need a positional embedding')

@@ -508,3 +508,72 @@ def prof_collect(kind: int = -1) -> Tuple[int, float, float]:
     _lib.check(_lib.lib().qcn_prof_collect(int(kind), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)),
                'qcn_prof_collect')
     return int(n.value), float(ms.value), float(b.value)
+
+
+RHAT_SPLIT_SCALE_LOG2 = 11      # |rhat| <= sqrt(127): rhat * 2^11 stays inside f16
+
+
+def split_rows(x: torch.Tensor, scale_log2: int = RHAT_SPLIT_SCALE_LOG2) -> torch.Tensor:
+    """qcn_split_rows_f16: fp32 rows [N, 128] -> split-f16 rows [N, 256] = [hi | lo] with hi + lo = x * 2^scale_log2."""
+    dev = x.device
+    _require(x, 'x', torch.float32, dev, (None, C))
+    y = torch.empty(x.size(0), 2 * C, dtype=torch.float16, device=dev)
+    _lib.check(_lib.lib().qcn_split_rows_f16(_ptr(x), x.size(0), int(scale_log2), _ptr(y), _stream(dev)),
+               'qcn_split_rows_f16')
+    return y
+
+
+def _split_scaled(w: torch.Tensor):
+    """(hi, lo, sw): w * 2^sw = hi + lo in f16 with max |w| * 2^sw in [2^14, 2^15)."""
+    w = w.detach().float()
+    mx = float(w.abs().max())
+    sw = 0 if mx == 0.0 else 15 - int(torch.frexp(torch.tensor(mx))[1])
+    ws = torch.ldexp(w, torch.tensor(sw))
+    hi = ws.half()
+    lo = (ws - hi.float()).half()
+    return hi, lo, sw
+
+
+def pack_attn_modes(wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
+    """Weight pack of qcn_attn_modes_f32 (include/qcnet_hip.h): per head the MFMA fragments of wk / wv (the
+    positional projections with the LN_r scale folded in, [128 out, 128 in]) as split f16, then the two fp32
+    factors that undo the weight and rhat scaling."""
+    frags, scales = [], []
+    for w in (wk, wv):
+        hi, lo, sw = _split_scaled(w)
+        parts = [t.view(8, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).reshape(8, 4, 64, 8) for t in (hi, lo)]
+        frags.append(torch.stack(parts, dim=2))                       # [head, ks, part, lane, 8]
+        scales.append(2.0 ** -(sw + RHAT_SPLIT_SCALE_LOG2))
+    body = torch.stack(frags, dim=1).contiguous()                       # [head, mat, ks, part, lane, 8]
+    tail = torch.tensor(scales, dtype=torch.float32, device=body.device)
+    pack = torch.cat([body.view(torch.uint8).reshape(-1), tail.view(torch.uint8).reshape(-1)]).contiguous()
+    assert pack.numel() == _lib.lib().qcn_attn_modes_pack_bytes()
+    return pack
+
+
+def attn_modes(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat_split: torch.Tensor, rowptr: torch.Tensor,
+               col: torch.Tensor, eid: Optional[torch.Tensor], wpack: torch.Tensor, bv: torch.Tensor,
+               rep: int, layout: int, col_shift: int = 0) -> torch.Tensor:
+    """qcn_attn_modes_f32: attention propagate of a mode-replicated relation (rep <= 6 queries per CSR row share its
+    edges) on the matrix cores; same result as attn_fused on the same graph."""
+    dev = q.device
+    n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
+    n_rows = rowptr.numel() - 1
+    _require(q, 'q', torch.float32, dev, (n_dst, C))
+    _require(k, 'k', torch.float32, dev, (n_src, C))
+    _require(v, 'v', torch.float32, dev, (n_src, C))
+    _require(rhat_split, 'rhat_split', torch.float16, dev, (None if eid is not None else num_edges, 2 * C))
+    _require(rowptr, 'rowptr', torch.int32, dev, (n_rows + 1,))
+    _require(col, 'col', torch.int32, dev, (num_edges,))
+    if eid is not None:
+        _require(eid, 'eid', torch.int32, dev, (num_edges,))
+    _require(wpack, 'wpack', torch.uint8, dev, (_lib.lib().qcn_attn_modes_pack_bytes(),))
+    _require(bv, 'bv', torch.float32, dev, (C,))
+    if n_rows * rep != n_dst or layout not in (LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR):
+        raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d) or plain layout' % (n_rows, rep, n_dst))
+    out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_attn_modes_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat_split), _ptr(rowptr), _ptr(col),
+                                             _ptr(eid), _ptr(wpack), _ptr(bv), n_dst, n_src, n_rows, num_edges,
+                                             int(rep), int(layout), int(col_shift), _ptr(out), _stream(dev)),
+               'qcn_attn_modes_f32')
+    return out

@@ -202,6 +202,48 @@ def test_attn_fused_mode_replication_equals_explicit_graph(layout):
     assert rel_err(got, want) < 2e-5
 
 
+def _modes(q, k, v, r, graph, w_kr, w_vr, b_vr, gamma, beta, rep, layout):
+    wpack = ops.pack_attn_modes((w_kr * gamma[None]).to(DEV), (w_vr * gamma[None]).to(DEV))
+    bv = (w_vr @ beta + b_vr).to(DEV).contiguous()
+    rs = ops.split_rows(ops.row_normalize(r.to(DEV)))
+    return ops.attn_modes(q.to(DEV), k.to(DEV), v.to(DEV), rs, graph.rowptr, graph.col, graph.eid, wpack, bv, rep, layout)
+
+
+@pytest.mark.parametrize('layout,K,n_rows,n_src,E,heavy,empty_from', [
+    (2, 6, 37, 50, 900, 100, 30),
+    (1, 6, 37, 50, 900, 100, 30),
+    (2, 6, 3000, 400, 90000, 300, None),     # more rows than workgroups, rows of 1..300+ edges (many tiles per row)
+    (2, 4, 64, 20, 700, None, None),
+    (2, 6, 5, 9, 0, None, None),
+])
+def test_attn_modes_vs_fp64_oracle(layout, K, n_rows, n_src, E, heavy, empty_from):
+    """qcn_attn_modes_f32 (mode-replicated relations on the matrix cores) against the fp64 oracle on the explicitly
+    K-times replicated graph, and against qcn_attn_fused_f32 on the same inputs.  Tolerance 2e-5 relative."""
+    base = _graph(n_src, n_rows, E, 43, heavy=heavy, empty_from=empty_from)
+    q, k, v, r = _feat(n_rows * K, 1, 1.5), _feat(n_src, 2, 1.5), _feat(n_src, 3), _feat(E, 4, 2.0)
+    pw = _pos_weights(12)
+    g = CSRGraph.from_edge_index(base.to(DEV), n_src, n_rows).replicate(K, layout)
+    got = _modes(q, k, v, r, g, *pw, rep=K, layout=layout)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all()
+    if E == 0:
+        assert bool((got == 0).all())
+        return
+    if layout == 1:
+        full = torch.cat([torch.stack([base[0], base[1] + m * n_rows]) for m in range(K)], dim=1)
+        r_full = r.repeat(K, 1)
+    else:
+        full = torch.stack([base[0].repeat_interleave(K), (base[1][:, None] * K + torch.arange(K)[None]).reshape(-1)])
+        r_full = r.repeat_interleave(K, dim=0)
+    kr, vr = _materialise(r_full, *pw)
+    want = c_attention(q, k, v, kr, vr, full)
+    assert rel_err(got, want) < 2e-5
+    ref = _fused(q, k, v, r, g, *pw, rep=K, layout=layout)
+    assert rel_err(got, ref) < 2e-5
+    deg = torch.bincount(full[1], minlength=n_rows * K)
+    assert bool((got.cpu()[deg == 0] == 0).all())
+
+
 @pytest.mark.parametrize('mode,h0_scale', [(0, 0.3), (1, 0.3), (1, 5.0)])
 def test_gru_kernel_matches_torch_gru(mode, h0_scale, restore_matmul_mode):
     """qcn_gru_f32 + input GEMM against torch.nn.GRU (CPU fp32), ragged sequence count (tail block), in both matmul
