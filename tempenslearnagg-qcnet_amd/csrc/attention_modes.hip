@@ -24,6 +24,7 @@
 // per destination (q in, out) — the same figure as qcn_attn_fused_f32.
 #include "common.hip.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -88,34 +89,41 @@ struct Tile {
 struct TileIdx {                   // per-lane indices of a tile (clamped to valid edges)
     int rid;                       // rhat row of the edge this lane copies by DMA
     int cole;                      // source row of edge (lane & 15)
-    int colv[4];                   // source rows of edges 4 g .. 4 g + 3
 };
 
 template <bool HAS_EID>
 __device__ __forceinline__ TileIdx load_tile_idx(const ModesArgs &a, const Tile &t, int wave, int lane)
 {
     TileIdx x;
-    const int i = lane & 15, g = lane >> 4, last = t.end - 1;
+    const int last = t.end - 1;
     const int jd = min(t.j0 + 2 * wave + (lane >> 5), last);
     x.rid = HAS_EID ? a.eid[jd] : jd;
-    x.cole = a.col[min(t.j0 + i, last)] - a.col_shift;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) x.colv[r] = a.col[min(t.j0 + 4 * g + r, last)] - a.col_shift;
+    x.cole = a.col[min(t.j0 + (lane & 15), last)] - a.col_shift;
     return x;
 }
 
 struct TileRows {
     f32x4 kf;                      // k[col_e][16 w + 4 g .. + 3]
     float vf[4];                   // v[col_{4 g + r}][16 w + i]
+    f32x4 qf;                      // q[node(row, mode = i)][16 w + 4 g .. + 3] (lanes with i < rep)
 };
 
-__device__ __forceinline__ TileRows load_tile_rows(const ModesArgs &a, const TileIdx &x, int wave, int lane)
+__device__ __forceinline__ int64_t node_of(const ModesArgs &a, int row, int mode)
+{
+    return a.layout == 1 ? (int64_t)mode * a.n_rows + row : (int64_t)row * a.rep + mode;
+}
+
+__device__ __forceinline__ TileRows load_tile_rows(const ModesArgs &a, const TileIdx &x, int row, int wave, int lane)
 {
     TileRows r;
     const int i = lane & 15, g = lane >> 4;
     r.kf = *reinterpret_cast<const f32x4 *>(a.k + (int64_t)x.cole * kC + 16 * wave + 4 * g);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) r.vf[t] = a.v[(int64_t)x.colv[t] * kC + 16 * wave + i];
+    for (int t = 0; t < 4; ++t) {
+        const int cv = __shfl(x.cole, 4 * g + t);       // source row of edge 4 g + t (held by lane 4 g + t)
+        r.vf[t] = a.v[(int64_t)cv * kC + 16 * wave + i];
+    }
+    r.qf = *reinterpret_cast<const f32x4 *>(a.q + node_of(a, row, min(i, a.rep - 1)) * kC + 16 * wave + 4 * g);
     return r;
 }
 
@@ -125,15 +133,25 @@ __device__ __forceinline__ void issue_tile_dma(const ModesArgs &a, const TileIdx
     const int e = 2 * wave + (lane >> 5), pc = lane & 31;
     const int c = (pc & 15) ^ e;                       // logical 16-B chunk inside the hi (pc < 16) or lo half
     const _Float16 *src = a.rs + (int64_t)x.rid * 256 + (pc >> 4) * 128 + c * 8;
+    __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)(buf + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// rowptr is read through the scalar unit (constant address space: it is not written during the launch, which the
+// compiler cannot see through the struct argument) — a vector load here would put a vmcnt(0) into the tile pipeline
+__device__ __forceinline__ int rowptr_at(const ModesArgs &a, int row)
+{
+    using cint = const __attribute__((address_space(4))) int32_t;
+    return *((cint *)(uintptr_t)a.rowptr + row);
 }
 
 // first tile of the first non-empty row in [row, row_end)
 __device__ __forceinline__ Tile first_tile(const ModesArgs &a, int row, int row_end)
 {
     while (row < row_end) {
-        const int b = a.rowptr[row], e = a.rowptr[row + 1];
+        const int b = rowptr_at(a, row), e = rowptr_at(a, row + 1);
         if (e > b) return Tile{row, b, e, true};
         ++row;
     }
@@ -147,11 +165,30 @@ __device__ __forceinline__ Tile next_tile(const ModesArgs &a, Tile t, int row_en
     return first_tile(a, t.row + 1, row_end);
 }
 
+// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = imm[15:14]:imm[3:0]; expcnt / lgkmcnt fields left at "no wait")
+constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+
+template <int S> struct Phase {};
+
+// kDepth tiles are in flight behind the one being computed: the tile computed in iteration n had its rhat DMA and its
+// k / v / q row loads issued in iteration n - kDepth, with indices loaded in iteration n - 2 kDepth.  Ring slots
+// (tile n -> slot n % kBufs) are compile-time constants in the kBufs-times unrolled loop, and every LDS image is a
+// __shared__ variable of its own, so that neither register copies nor the compiler's LDS-DMA alias waits drain the
+// queue early.  Every iteration issues the same kOps vector-memory loads (clamped duplicates past the last tile); the
+// one manual wait per iteration, vmcnt((kDepth - 1) kOps), retires the DMA of the NEXT tile and leaves the younger
+// iterations' loads in flight.
+constexpr int kDepth = 2;
+constexpr int kBufs = kDepth + 1;
+
 template <bool HAS_EID>
 __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 {
-    __shared__ __attribute__((aligned(16))) unsigned char s_r[2][kTile * kRowBytes];      // rhat tile images
+    static_assert(kBufs == 3, "one __shared__ image per ring slot below");
+    __shared__ __attribute__((aligned(16))) unsigned char s_r0[kTile * kRowBytes];       // rhat tile images
+    __shared__ __attribute__((aligned(16))) unsigned char s_r1[kTile * kRowBytes];
+    __shared__ __attribute__((aligned(16))) unsigned char s_r2[kTile * kRowBytes];
     __shared__ __attribute__((aligned(16))) float s_t[kHeads][16 * kTStride];            // alpha transposition
+    constexpr int kOps = (HAS_EID ? 2 : 1) + 1 + 6;      // index loads + DMA + k, 4 v, q row loads per iteration
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -180,56 +217,68 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
     float *const s_tw = s_t[wave];
 
     // rows without edges produce zeros (PyG softmax over an empty segment, attention_layer.py:118)
-    auto node_of = [&](int row, int mode) -> int64_t {
-        return a.layout == 1 ? (int64_t)mode * a.n_rows + row : (int64_t)row * a.rep + mode;
-    };
     for (int row = row_begin; row < row_end; ++row) {
-        if (a.rowptr[row + 1] > a.rowptr[row]) continue;
+        if (rowptr_at(a, row + 1) > rowptr_at(a, row)) continue;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mode = 4 * g + r;
-            if (mode < a.rep) a.out[node_of(row, mode) * kC + 16 * wave + i] = 0.f;
+            if (mode < a.rep) a.out[node_of(a, row, mode) * kC + 16 * wave + i] = 0.f;
         }
     }
 
-    Tile t0 = first_tile(a, row_begin, row_end);
-    if (t0.row < 0) return;
-    Tile t1 = next_tile(a, t0, row_end);
-    TileIdx x0 = load_tile_idx<HAS_EID>(a, t0, wave, lane);
-    TileIdx x1 = x0;
-    if (t1.row >= 0) x1 = load_tile_idx<HAS_EID>(a, t1, wave, lane);
-    issue_tile_dma(a, x0, s_r[0], wave, lane);
-    TileRows r0 = load_tile_rows(a, x0, wave, lane);
-    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    Tile tl[2 * kDepth + 1];
+    tl[0] = first_tile(a, row_begin, row_end);
+    if (tl[0].row < 0) return;
+#pragma unroll
+    for (int j = 1; j <= 2 * kDepth; ++j) tl[j] = next_tile(a, tl[j - 1], row_end);
+
+    TileRows rows[kBufs];
+    TileIdx idx[kBufs];
+    auto image = [&](auto ph) -> unsigned char * {
+        constexpr int S = decltype(ph)::value;
+        return S == 0 ? s_r0 : (S == 1 ? s_r1 : s_r2);
+    };
+    auto safe = [&](const Tile &t) -> Tile { return t.row >= 0 ? t : tl[0]; };
+    // prologue: tiles 0 .. kDepth - 1 completely, indices of tiles kDepth .. 2 kDepth - 1
+    {
+        const Tile ta = safe(tl[0]), tb = safe(tl[1]);
+        const TileIdx xa = load_tile_idx<HAS_EID>(a, ta, wave, lane), xb = load_tile_idx<HAS_EID>(a, tb, wave, lane);
+        issue_tile_dma(a, xa, s_r0, wave, lane);
+        rows[0] = load_tile_rows(a, xa, ta.row, wave, lane);
+        issue_tile_dma(a, xb, s_r1, wave, lane);
+        rows[1] = load_tile_rows(a, xb, tb.row, wave, lane);
+        idx[2] = load_tile_idx<HAS_EID>(a, safe(tl[2]), wave, lane);
+        idx[0] = load_tile_idx<HAS_EID>(a, safe(tl[3]), wave, lane);
+        rows[2] = rows[1];
+        idx[1] = idx[0];
+    }
+    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
     __syncthreads();
 
     f32x4 qa = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
     float m[4], l[4];
-    int buf = 0;
-    while (true) {
-        // ---- stage B: DMA + rows of the next tile; stage C: indices of the one after
-        Tile t2 = next_tile(a, t1, row_end);
-        TileRows r1 = r0;
-        TileIdx x2 = x1;
-        if (t1.row >= 0) {
-            issue_tile_dma(a, x1, s_r[buf ^ 1], wave, lane);
-            r1 = load_tile_rows(a, x1, wave, lane);
-        }
-        if (t2.row >= 0) x2 = load_tile_idx<HAS_EID>(a, t2, wave, lane);
 
-        // ---- stage A: the current tile
+    // one iteration with the current tile in ring slot S; returns true after the last tile
+    auto step = [&](auto ph) -> bool {
+        constexpr int S = decltype(ph)::value;
+        constexpr int SB = (S + kDepth) % kBufs;          // slot of the tile kDepth ahead (DMA + rows now)
+        constexpr int SC = (S + 2 * kDepth) % kBufs;      // slot of the indices loaded now
+        const Tile t0 = tl[0], tb = safe(tl[kDepth]), tc = safe(tl[2 * kDepth]);
+        const Tile tn = next_tile(a, tl[2 * kDepth], row_end);
+        issue_tile_dma(a, idx[SB], image(std::integral_constant<int, SB>{}), wave, lane);
+        rows[SB] = load_tile_rows(a, idx[SB], tb.row, wave, lane);
+        idx[SC] = load_tile_idx<HAS_EID>(a, tc, wave, lane);
+
+        // ---- the current tile
         if (t0.first) {
-            qa = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (i < a.rep) {
-                qa = *reinterpret_cast<const f32x4 *>(a.q + node_of(t0.row, i) * kC + 16 * wave + 4 * g);
-                qa *= 0.25f * kLog2e;          // head_dim ** -0.5 (layers/attention_layer.py:38), logits in base 2
-            }
+            qa = rows[S].qf * (0.25f * kLog2e);   // head_dim ** -0.5 (layers/attention_layer.py:38), logits in base 2
+            if (i >= a.rep) qa = f32x4{0.f, 0.f, 0.f, 0.f};
             o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
         }
         f32x4 kk = {0.f, 0.f, 0.f, 0.f}, kx = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-        const unsigned char *img = s_r[buf] + i * kRowBytes;
+        const unsigned char *img = image(ph) + i * kRowBytes;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int off = 16 * ((4 * ks + g) ^ i);
@@ -245,47 +294,61 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         // kk^T[d = 4 g + r][e = i], vv[e = 4 g + r][d = i]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            kk[r] = fmaf(kk[r] + kx[r], usc_k, r0.kf[r]);
-            vv[r] = fmaf(vv[r] + vx[r], usc_v, r0.vf[r]);
+            kk[r] = fmaf(kk[r] + kx[r], usc_k, rows[S].kf[r]);
+            vv[r] = fmaf(vv[r] + vx[r], usc_v, rows[S].vf[r]);
         }
-        f32x4 p = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], kk[r], p, 0, 0, 0);
+        f32x4 p = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0], kk[0], p, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1], kk[1], p2, 0, 0, 0);
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[2], kk[2], p, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[3], kk[3], p2, 0, 0, 0);
+        p += p2;
         // p[r] = logit[mode = 4 g + r][e = i]
         const bool valid = t0.j0 + i < t0.end;
-        float corr[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float pv = valid ? p[r] : -INFINITY;
             const float mn = fmaxf(m[r], row16_max(pv));
-            corr[r] = __builtin_amdgcn_exp2f(m[r] - mn);
+            const float corr = __builtin_amdgcn_exp2f(m[r] - mn);
             m[r] = mn;
             p[r] = __builtin_amdgcn_exp2f(pv - mn);
-            l[r] = fmaf(l[r], corr[r], p[r]);
-            o[r] *= corr[r];
+            l[r] = fmaf(l[r], corr, p[r]);
+            o[r] *= corr;
             s_tw[(4 * g + r) * kTStride + i] = p[r];
         }
         wave_lds_fence();
         const f32x4 pa = *reinterpret_cast<const f32x4 *>(s_tw + i * kTStride + 4 * g);   // alpha[mode = i][e = 4 g + r]
         wave_lds_fence();
-#pragma unroll
-        for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vv[r], o, 0, 0, 0);
+        f32x4 o2 = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], vv[0], o, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], vv[1], o2, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[2], vv[2], o, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[3], vv[3], o2, 0, 0, 0);
+        o += o2;
 
-        const bool last = t1.row != t0.row;
-        if (last) {
+        if (tl[1].row != t0.row) {                              // last tile of its row
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ls = row16_sum(l[r]);
                 const float inv = 1.0f / (ls + 1e-16f);         // PyG softmax denominator
                 const int mode = 4 * g + r;
-                if (mode < a.rep) a.out[node_of(t0.row, mode) * kC + 16 * wave + i] = fmaf(o[r], inv, ls * inv * bias);
+                if (mode < a.rep) a.out[node_of(a, t0.row, mode) * kC + 16 * wave + i] = fmaf(o[r], inv, ls * inv * bias);
             }
         }
-        if (t1.row < 0) break;
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the next tile's DMA, rows and the indices after it
-        __syncthreads();
-        t0 = t1; t1 = t2; x1 = x2; r0 = r1;
-        buf ^= 1;
+        if (tl[1].row < 0) return true;
+        // the next tile's DMA has landed (vmcnt) and this wave's LDS reads are done (lgkmcnt 0); a raw barrier:
+        // __syncthreads() would add a release fence, i.e. vmcnt(0)
+        __builtin_amdgcn_s_waitcnt(vmcnt_imm((kDepth - 1) * kOps) & ~0x0F00);
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int j = 0; j < 2 * kDepth; ++j) tl[j] = tl[j + 1];
+        tl[2 * kDepth] = tn;
+        return false;
+    };
+    while (true) {
+        if (step(std::integral_constant<int, 0>{})) break;
+        if (step(std::integral_constant<int, 1>{})) break;
+        if (step(std::integral_constant<int, 2>{})) break;
     }
 }
 
