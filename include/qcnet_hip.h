@@ -134,14 +134,16 @@ int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const flo
  *     frag[lane][j] = W[16 head + (lane & 15)][32 kstep + 8 (lane >> 4) + j] * 2^sw  (wk, wv as in qcn_attn_fused_f32,
  *     sw = the power of two that puts max |W| into [2^14, 2^15)), then two fp32: 2^-(sw_k + 11), 2^-(sw_v + 11)
  *     (host: ops.pack_attn_modes);
- *   the other arguments as in qcn_attn_fused_f32 (no row_index / src_offset).
+ *   n_feat_rows = rows of rhat_split (>= num_edges without eid; every eid entry < n_feat_rows);
+ *   the other arguments as in qcn_attn_fused_f32 (no row_index / src_offset).  Rows are addressed by 32-bit byte
+ *   offsets: n_dst, n_src, n_feat_rows < 2^23, else QCN_ERR_UNSUPPORTED (use qcn_attn_fused_f32).
  * Logits and the weighted sums are exact-fp32 MFMAs; |k + to_k_r(.)| is not limited. */
 int qcn_split_rows_f16(const float *x, int64_t n_rows, int scale_log2, void *y, void *stream);
 size_t qcn_attn_modes_pack_bytes(void);
 int qcn_attn_modes_f32(const float *q, const float *k, const float *v, const void *rhat_split,
                        const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                        const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
-                       int rep, int layout, int64_t col_shift, float *out, void *stream);
+                       int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream);
 
 /* Arithmetic of the three MFMA chain kernels below (qcn_fourier_embed_f32, qcn_ln_linear_f32, qcn_attn_post_f32).
  *   QCN_MATMUL_EXACT_F32: v_mfma_f32_32x32x2_f32, exact fp32 fma chains.

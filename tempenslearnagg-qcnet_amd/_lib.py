@@ -46,8 +46,8 @@ def _declare(lib) -> None:
     lib.qcn_attn_modes_pack_bytes.restype = c_size_t
     lib.qcn_attn_modes_pack_bytes.argtypes = []
     lib.qcn_attn_modes_f32.restype = c_int
-    lib.qcn_attn_modes_f32.argtypes = [P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
-                                       c_int64, P, P]
+    lib.qcn_attn_modes_f32.argtypes = [P, P, P, P, P, P, P, P, P, c_int64, c_int64, c_int64, c_int64, c_int64, c_int,
+                                       c_int, c_int64, P, P]
     lib.qcn_fourier_pack_floats.restype = c_size_t
     lib.qcn_fourier_pack_floats.argtypes = [c_int]
     lib.qcn_fourier_embed_f32.restype = c_int

@@ -86,56 +86,61 @@ struct Tile {
     bool first;                    // first tile of its row
 };
 
-struct TileIdx {                   // per-lane indices of a tile (clamped to valid edges)
-    int rid;                       // rhat row of the edge this lane copies by DMA
-    int cole;                      // source row of edge (lane & 15)
+struct TileIdx {                   // indices of the edge whose rows this lane copies by DMA (clamped to valid edges)
+    int rid;                       // its rhat row
+    int src;                       // its source row (k / v)
 };
+
+// all global addresses are base (uniform) + 32-bit byte offset: the launcher refuses tables of 4 GiB and more
+template <typename T>
+__device__ __forceinline__ T ld_off(const void *base, uint32_t byte_off)
+{
+    return *reinterpret_cast<const T *>(static_cast<const char *>(base) + byte_off);
+}
 
 template <bool HAS_EID>
 __device__ __forceinline__ TileIdx load_tile_idx(const ModesArgs &a, const Tile &t, int wave, int lane)
 {
     TileIdx x;
-    const int last = t.end - 1;
-    const int jd = min(t.j0 + 2 * wave + (lane >> 5), last);
-    x.rid = HAS_EID ? a.eid[jd] : jd;
-    x.cole = a.col[min(t.j0 + (lane & 15), last)] - a.col_shift;
+    const int jd = min(t.j0 + 2 * wave + (lane >> 5), t.end - 1);
+    x.rid = HAS_EID ? ld_off<int>(a.eid, 4u * (uint32_t)jd) : jd;
+    x.src = ld_off<int>(a.col, 4u * (uint32_t)jd) - a.col_shift;
     return x;
 }
 
-struct TileRows {
-    f32x4 kf;                      // k[col_e][16 w + 4 g .. + 3]
-    float vf[4];                   // v[col_{4 g + r}][16 w + i]
-    f32x4 qf;                      // q[node(row, mode = i)][16 w + 4 g .. + 3] (lanes with i < rep)
+__device__ __forceinline__ uint32_t node_of(const ModesArgs &a, int row, int mode)
+{
+    return a.layout == 1 ? (uint32_t)mode * (uint32_t)a.n_rows + (uint32_t)row : (uint32_t)row * (uint32_t)a.rep + (uint32_t)mode;
+}
+
+// q[node(row, mode = i)][16 w + 4 g .. + 3] (lanes with i >= rep read mode rep - 1 and are zeroed at the use)
+__device__ __forceinline__ f32x4 load_q(const ModesArgs &a, int row, int wave, int lane)
+{
+    const int i = lane & 15, g = lane >> 4;
+    return ld_off<f32x4>(a.q, node_of(a, row, min(i, a.rep - 1)) * 512u + 64u * wave + 16u * g);
+}
+
+// One ring slot: the tile's 16 rhat rows (split f16), 16 k rows and 16 v rows (fp32), 512 B each, as 16-B chunks with
+// chunk c of row e stored at c ^ e (rhat: inside its hi / lo half).  Wave w copies rows 2 w, 2 w + 1 of each image.
+struct Slot {
+    unsigned char r[kTile * kRowBytes], k[kTile * kRowBytes], v[kTile * kRowBytes];
 };
 
-__device__ __forceinline__ int64_t node_of(const ModesArgs &a, int row, int mode)
-{
-    return a.layout == 1 ? (int64_t)mode * a.n_rows + row : (int64_t)row * a.rep + mode;
-}
-
-__device__ __forceinline__ TileRows load_tile_rows(const ModesArgs &a, const TileIdx &x, int row, int wave, int lane)
-{
-    TileRows r;
-    const int i = lane & 15, g = lane >> 4;
-    r.kf = *reinterpret_cast<const f32x4 *>(a.k + (int64_t)x.cole * kC + 16 * wave + 4 * g);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int cv = __shfl(x.cole, 4 * g + t);       // source row of edge 4 g + t (held by lane 4 g + t)
-        r.vf[t] = a.v[(int64_t)cv * kC + 16 * wave + i];
-    }
-    r.qf = *reinterpret_cast<const f32x4 *>(a.q + node_of(a, row, min(i, a.rep - 1)) * kC + 16 * wave + 4 * g);
-    return r;
-}
-
-// wave w copies LDS chunks [64 w, 64 w + 64) of the tile image: row e = 2 w + (lane >> 5), physical chunk lane & 31
-__device__ __forceinline__ void issue_tile_dma(const ModesArgs &a, const TileIdx &x, unsigned char *buf, int wave, int lane)
+__device__ __forceinline__ void issue_tile_dma(const ModesArgs &a, const TileIdx &x, Slot *slot, int wave, int lane)
 {
     const int e = 2 * wave + (lane >> 5), pc = lane & 31;
-    const int c = (pc & 15) ^ e;                       // logical 16-B chunk inside the hi (pc < 16) or lo half
-    const _Float16 *src = a.rs + (int64_t)x.rid * 256 + (pc >> 4) * 128 + c * 8;
+    const uint32_t cr = (uint32_t)(((pc & 15) ^ e) | (pc & 16));     // rhat: logical chunk (hi half 0..15, lo half 16..31)
+    const uint32_t ck = (uint32_t)(pc ^ e);                          // k / v: logical chunk
+    const char *sr = reinterpret_cast<const char *>(a.rs) + ((uint32_t)x.rid * 512u + cr * 16u);
+    const char *sk = reinterpret_cast<const char *>(a.k) + ((uint32_t)x.src * 512u + ck * 16u);
+    const char *sv = reinterpret_cast<const char *>(a.v) + ((uint32_t)x.src * 512u + ck * 16u);
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                     (__attribute__((address_space(3))) void *)(buf + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sr,
+                                     (__attribute__((address_space(3))) void *)(slot->r + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sk,
+                                     (__attribute__((address_space(3))) void *)(slot->k + wave * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sv,
+                                     (__attribute__((address_space(3))) void *)(slot->v + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -165,30 +170,67 @@ __device__ __forceinline__ Tile next_tile(const ModesArgs &a, Tile t, int row_en
     return first_tile(a, t.row + 1, row_end);
 }
 
-// s_waitcnt vmcnt(n) alone (gfx9 encoding: vmcnt = imm[15:14]:imm[3:0]; expcnt / lgkmcnt fields left at "no wait")
-constexpr int vmcnt_imm(int n) { return 0x0F70 | (n & 15) | ((n >> 4) << 14); }
+// s_waitcnt vmcnt(n) lgkmcnt(0) (gfx9 encoding: vmcnt = imm[15:14]:imm[3:0], lgkmcnt = imm[11:8], expcnt untouched)
+constexpr int wait_imm(int n) { return 0x0070 | (n & 15) | ((n >> 4) << 14); }
 
-template <int S> struct Phase {};
+// max over the 16 lanes of every DPP row, four independent values at once (one v_max_f32_dpp per value and step; the
+// other three values between two steps of one value cover the VALU -> DPP wait states)
+__device__ __forceinline__ void row16_max4(float (&v)[4])
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_max_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
 
-// kDepth tiles are in flight behind the one being computed: the tile computed in iteration n had its rhat DMA and its
-// k / v / q row loads issued in iteration n - kDepth, with indices loaded in iteration n - 2 kDepth.  Ring slots
-// (tile n -> slot n % kBufs) are compile-time constants in the kBufs-times unrolled loop, and every LDS image is a
+// Software pipeline.  In iteration n a wave
+//   * issues the three DMAs (rhat, k, v rows) and the q load of tile n + kDepth, and the index loads of tile
+//     n + kDepth + kIdxAhead,
+//   * runs the softmax / weighted-sum half of tile n out of registers (kk, vv of the previous iteration), interleaved
+//     with the projection MFMAs of tile n + 1 (ring slot (n + 1) % kBufs): the MFMA pipe works on the next tile while
+//     the vector ALU does the exp / max / rescale chain of the current one,
+//   * waits until the DMAs of tile n + 2 have landed (vmcnt((kDepth - 2) kOps): the younger iterations' loads stay in
+//     flight) and meets the other seven waves at one raw s_barrier.
+// Ring slots (tile t -> slot t % kBufs) are compile-time constants in the kBufs-times unrolled loop and every slot is a
 // __shared__ variable of its own, so that neither register copies nor the compiler's LDS-DMA alias waits drain the
-// queue early.  Every iteration issues the same kOps vector-memory loads (clamped duplicates past the last tile); the
-// one manual wait per iteration, vmcnt((kDepth - 1) kOps), retires the DMA of the NEXT tile and leaves the younger
-// iterations' loads in flight.
-constexpr int kDepth = 2;
+// queue.  Every iteration issues the same kOps vector-memory loads (clamped duplicates past the last tile).
+#ifndef QCN_MODES_DEPTH
+#define QCN_MODES_DEPTH 3
+#endif
+constexpr int kDepth = QCN_MODES_DEPTH;   // 3 .. 5
 constexpr int kBufs = kDepth + 1;
+constexpr int kIdxAhead = 2;
 
 template <bool HAS_EID>
 __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 {
-    static_assert(kBufs == 3, "one __shared__ image per ring slot below");
-    __shared__ __attribute__((aligned(16))) unsigned char s_r0[kTile * kRowBytes];       // rhat tile images
-    __shared__ __attribute__((aligned(16))) unsigned char s_r1[kTile * kRowBytes];
-    __shared__ __attribute__((aligned(16))) unsigned char s_r2[kTile * kRowBytes];
+    static_assert(kBufs >= 4 && kBufs <= 6, "one __shared__ slot per ring position below");
+    __shared__ __attribute__((aligned(16))) Slot s_0;
+    __shared__ __attribute__((aligned(16))) Slot s_1;
+    __shared__ __attribute__((aligned(16))) Slot s_2;
+    __shared__ __attribute__((aligned(16))) Slot s_3;
+    struct Unused { unsigned char pad[16]; };
+    __shared__ __attribute__((aligned(16))) std::conditional_t<(kBufs > 4), Slot, Unused> s_4;
+    __shared__ __attribute__((aligned(16))) std::conditional_t<(kBufs > 5), Slot, Unused> s_5;
     __shared__ __attribute__((aligned(16))) float s_t[kHeads][16 * kTStride];            // alpha transposition
-    constexpr int kOps = (HAS_EID ? 2 : 1) + 1 + 6;      // index loads + DMA + k, 4 v, q row loads per iteration
+    constexpr int kOps = (HAS_EID ? 2 : 1) + 3 + 1;      // index loads + 3 DMAs + q per iteration
+    constexpr int kTiles = kDepth + kIdxAhead + 1;       // tile descriptors carried: n .. n + kDepth + kIdxAhead
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -215,6 +257,16 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
     const float usc_k = scales[0], usc_v = scales[1];
     const float bias = a.bv[16 * wave + i];
     float *const s_tw = s_t[wave];
+    const uint32_t out_lane = 64u * wave + 4u * i;        // byte offset of this lane's channel inside an output row
+
+    // per-lane LDS byte offsets inside a slot (tile independent)
+    int r_off[4], v_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) r_off[ks] = i * kRowBytes + 16 * ((4 * ks + g) ^ i);              // rhat: row i, chunk 4 ks + g
+    const int k_off = i * kRowBytes + 16 * ((4 * wave + g) ^ i);                                      // k: row i, floats 16 w + 4 g ..
+#pragma unroll
+    for (int t = 0; t < 4; ++t)                                                                       // v: row 4 g + t, float 16 w + i
+        v_off[t] = (4 * g + t) * kRowBytes + 16 * ((4 * wave + (i >> 2)) ^ (4 * g + t)) + 4 * (i & 3);
 
     // rows without edges produce zeros (PyG softmax over an empty segment, attention_layer.py:118)
     for (int row = row_begin; row < row_end; ++row) {
@@ -222,133 +274,184 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int mode = 4 * g + r;
-            if (mode < a.rep) a.out[node_of(a, row, mode) * kC + 16 * wave + i] = 0.f;
+            if (mode < a.rep) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, row, mode) * 512u + out_lane)) = 0.f;
         }
     }
 
-    Tile tl[2 * kDepth + 1];
+    Tile tl[kTiles];
     tl[0] = first_tile(a, row_begin, row_end);
     if (tl[0].row < 0) return;
 #pragma unroll
-    for (int j = 1; j <= 2 * kDepth; ++j) tl[j] = next_tile(a, tl[j - 1], row_end);
+    for (int j = 1; j < kTiles; ++j) tl[j] = next_tile(a, tl[j - 1], row_end);
 
-    TileRows rows[kBufs];
+    f32x4 qring[kBufs];
     TileIdx idx[kBufs];
-    auto image = [&](auto ph) -> unsigned char * {
+    auto slot_of = [&](auto ph) -> Slot * {
         constexpr int S = decltype(ph)::value;
-        return S == 0 ? s_r0 : (S == 1 ? s_r1 : s_r2);
+        if constexpr (S == 0) return &s_0;
+        else if constexpr (S == 1) return &s_1;
+        else if constexpr (S == 2) return &s_2;
+        else if constexpr (S == 3) return &s_3;
+        else if constexpr (S == 4) return reinterpret_cast<Slot *>(&s_4);
+        else return reinterpret_cast<Slot *>(&s_5);
     };
     auto safe = [&](const Tile &t) -> Tile { return t.row >= 0 ? t : tl[0]; };
-    // prologue: tiles 0 .. kDepth - 1 completely, indices of tiles kDepth .. 2 kDepth - 1
-    {
-        const Tile ta = safe(tl[0]), tb = safe(tl[1]);
-        const TileIdx xa = load_tile_idx<HAS_EID>(a, ta, wave, lane), xb = load_tile_idx<HAS_EID>(a, tb, wave, lane);
-        issue_tile_dma(a, xa, s_r0, wave, lane);
-        rows[0] = load_tile_rows(a, xa, ta.row, wave, lane);
-        issue_tile_dma(a, xb, s_r1, wave, lane);
-        rows[1] = load_tile_rows(a, xb, tb.row, wave, lane);
-        idx[2] = load_tile_idx<HAS_EID>(a, safe(tl[2]), wave, lane);
-        idx[0] = load_tile_idx<HAS_EID>(a, safe(tl[3]), wave, lane);
-        rows[2] = rows[1];
-        idx[1] = idx[0];
-    }
-    __builtin_amdgcn_s_waitcnt(vmcnt_imm(0));
-    __syncthreads();
 
-    f32x4 qa = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+    // kk^T[d = 4 g + r][e = i] = usc_k W_kr[16 w + d, :] . rhat_e + k[src_e][16 w + d]
+    // vv[e = 4 g + r][d = i]   = usc_v rhat_e . W_vr[16 w + d, :] + v[src_e][16 w + d]      of the tile in `slot`;
+    // `between(ks)` is called after the MFMAs of k-step ks: the caller's vector-ALU work that overlaps them
+    auto project = [&](const Slot *slot, f32x4 &kk, f32x4 &vv, auto between) {
+        f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
+        kk = f32x4{0.f, 0.f, 0.f, 0.f};
+        vv = f32x4{0.f, 0.f, 0.f, 0.f};
+        half8 rh[4], rl[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            rh[ks] = *reinterpret_cast<const half8 *>(slot->r + r_off[ks]);
+            rl[ks] = *reinterpret_cast<const half8 *>(slot->r + r_off[ks] + 256);
+        }
+        const f32x4 kf = *reinterpret_cast<const f32x4 *>(slot->k + k_off);
+        float vf[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vf[r] = *reinterpret_cast<const float *>(slot->v + v_off[r]);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            kk = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_hi[ks], rh[ks], kk, 0, 0, 0);
+            vv = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ks], wv_hi[ks], vv, 0, 0, 0);
+            kx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_hi[ks], rl[ks], kx, 0, 0, 0);
+            vx = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl[ks], wv_hi[ks], vx, 0, 0, 0);
+            kx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_lo[ks], rh[ks], kx, 0, 0, 0);
+            vx = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh[ks], wv_lo[ks], vx, 0, 0, 0);
+            between(ks);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            kk[r] = fmaf(kk[r] + kx[r], usc_k, kf[r]);
+            vv[r] = fmaf(vv[r] + vx[r], usc_v, vf[r]);
+        }
+    };
+
+    // prologue: DMAs + q of tiles 0 .. kDepth - 1, indices of tiles kDepth .. kDepth + kIdxAhead - 1, projection of tile 0
+    {
+        auto fill = [&](auto ph) {
+            constexpr int J = decltype(ph)::value;
+            if constexpr (J < kDepth) {
+                const Tile t = safe(tl[J]);
+                const TileIdx x = load_tile_idx<HAS_EID>(a, t, wave, lane);
+                issue_tile_dma(a, x, slot_of(ph), wave, lane);
+                qring[J] = load_q(a, t.row, wave, lane);
+                idx[J] = x;
+            }
+        };
+        fill(std::integral_constant<int, 0>{}); fill(std::integral_constant<int, 1>{}); fill(std::integral_constant<int, 2>{});
+        fill(std::integral_constant<int, 3>{}); fill(std::integral_constant<int, 4>{});
+        qring[kDepth] = qring[0];
+#pragma unroll
+        for (int j = 0; j < kIdxAhead; ++j) idx[(kDepth + j) % kBufs] = load_tile_idx<HAS_EID>(a, safe(tl[kDepth + j]), wave, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(wait_imm(0));
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 qa = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f}, kk, vv;
     float m[4], l[4];
+    project(&s_0, kk, vv, [](int) {});
 
     // one iteration with the current tile in ring slot S; returns true after the last tile
     auto step = [&](auto ph) -> bool {
         constexpr int S = decltype(ph)::value;
-        constexpr int SB = (S + kDepth) % kBufs;          // slot of the tile kDepth ahead (DMA + rows now)
-        constexpr int SC = (S + 2 * kDepth) % kBufs;      // slot of the indices loaded now
-        const Tile t0 = tl[0], tb = safe(tl[kDepth]), tc = safe(tl[2 * kDepth]);
-        const Tile tn = next_tile(a, tl[2 * kDepth], row_end);
-        issue_tile_dma(a, idx[SB], image(std::integral_constant<int, SB>{}), wave, lane);
-        rows[SB] = load_tile_rows(a, idx[SB], tb.row, wave, lane);
+        constexpr int SN = (S + 1) % kBufs;                    // slot of the next tile (projected now)
+        constexpr int SB = (S + kDepth) % kBufs;               // slot of the tile kDepth ahead (DMAs + q now)
+        constexpr int SC = (S + kDepth + kIdxAhead) % kBufs;   // slot of the indices loaded now
+        const Tile t0 = tl[0], tb = safe(tl[kDepth]), tc = safe(tl[kTiles - 1]);
+        const Tile tn = next_tile(a, tl[kTiles - 1], row_end);
+        issue_tile_dma(a, idx[SB], slot_of(std::integral_constant<int, SB>{}), wave, lane);
+        qring[SB] = load_q(a, tb.row, wave, lane);
         idx[SC] = load_tile_idx<HAS_EID>(a, tc, wave, lane);
 
-        // ---- the current tile
         if (t0.first) {
-            qa = rows[S].qf * (0.25f * kLog2e);   // head_dim ** -0.5 (layers/attention_layer.py:38), logits in base 2
+            qa = qring[S] * (0.25f * kLog2e);     // head_dim ** -0.5 (layers/attention_layer.py:38), logits in base 2
             if (i >= a.rep) qa = f32x4{0.f, 0.f, 0.f, 0.f};
             o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
         }
-        f32x4 kk = {0.f, 0.f, 0.f, 0.f}, kx = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-        const unsigned char *img = image(ph) + i * kRowBytes;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int off = 16 * ((4 * ks + g) ^ i);
-            const half8 rh = *reinterpret_cast<const half8 *>(img + off);
-            const half8 rl = *reinterpret_cast<const half8 *>(img + 256 + off);
-            kk = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_hi[ks], rh, kk, 0, 0, 0);
-            vv = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh, wv_hi[ks], vv, 0, 0, 0);
-            kx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_hi[ks], rl, kx, 0, 0, 0);
-            vx = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl, wv_hi[ks], vx, 0, 0, 0);
-            kx = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_lo[ks], rh, kx, 0, 0, 0);
-            vx = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh, wv_lo[ks], vx, 0, 0, 0);
-        }
-        // kk^T[d = 4 g + r][e = i], vv[e = 4 g + r][d = i]
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            kk[r] = fmaf(kk[r] + kx[r], usc_k, rows[S].kf[r]);
-            vv[r] = fmaf(vv[r] + vx[r], usc_v, rows[S].vf[r]);
-        }
+        // ---- softmax / weighted sum of tile n (kk, vv in registers) around the projection MFMAs of tile n + 1
+        const f32x4 vcur = vv;
         f32x4 p = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
         p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0], kk[0], p, 0, 0, 0);
         p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1], kk[1], p2, 0, 0, 0);
         p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[2], kk[2], p, 0, 0, 0);
         p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[3], kk[3], p2, 0, 0, 0);
-        p += p2;
-        // p[r] = logit[mode = 4 g + r][e = i]
         const bool valid = t0.j0 + i < t0.end;
+        f32x4 pa;
+        f32x4 kk_n, vv_n;
+        project(slot_of(std::integral_constant<int, SN>{}), kk_n, vv_n, [&](int ks) {
+            if (ks == 0) {
+                // p[r] = logit[mode = 4 g + r][e = i]
+                p += p2;
+                float pv[4], mx[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float pv = valid ? p[r] : -INFINITY;
-            const float mn = fmaxf(m[r], row16_max(pv));
-            const float corr = __builtin_amdgcn_exp2f(m[r] - mn);
-            m[r] = mn;
-            p[r] = __builtin_amdgcn_exp2f(pv - mn);
-            l[r] = fmaf(l[r], corr, p[r]);
-            o[r] *= corr;
-            s_tw[(4 * g + r) * kTStride + i] = p[r];
-        }
-        wave_lds_fence();
-        const f32x4 pa = *reinterpret_cast<const f32x4 *>(s_tw + i * kTStride + 4 * g);   // alpha[mode = i][e = 4 g + r]
-        wave_lds_fence();
+                for (int r = 0; r < 4; ++r) { pv[r] = valid ? p[r] : -INFINITY; mx[r] = pv[r]; }
+                row16_max4(mx);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mn = fmaxf(m[r], mx[r]);
+                    const float corr = __builtin_amdgcn_exp2f(m[r] - mn);
+                    m[r] = mn;
+                    p[r] = __builtin_amdgcn_exp2f(pv[r] - mn);
+                    l[r] = fmaf(l[r], corr, p[r]);
+                    o[r] *= corr;
+                    s_tw[(4 * g + r) * kTStride + i] = p[r];
+                }
+            } else if (ks == 1) {
+                wave_lds_fence();
+                pa = *reinterpret_cast<const f32x4 *>(s_tw + i * kTStride + 4 * g);   // alpha[mode = i][e = 4 g + r]
+            } else if (ks == 2) {
+                wave_lds_fence();
+            }
+        });
         f32x4 o2 = {0.f, 0.f, 0.f, 0.f};
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], vv[0], o, 0, 0, 0);
-        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], vv[1], o2, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[2], vv[2], o, 0, 0, 0);
-        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[3], vv[3], o2, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], vcur[0], o, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], vcur[1], o2, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[2], vcur[2], o, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[3], vcur[3], o2, 0, 0, 0);
         o += o2;
+        kk = kk_n;
+        vv = vv_n;
 
-        if (tl[1].row != t0.row) {                              // last tile of its row
+        const bool last = tl[1].row != t0.row;                  // last tile of its row
+        if (last) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float ls = row16_sum(l[r]);
-                const float inv = 1.0f / (ls + 1e-16f);         // PyG softmax denominator
+                const float den = ls + 1e-16f;                  // PyG softmax denominator
+                float inv = __builtin_amdgcn_rcpf(den);
+                inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);    // one Newton step on the hardware reciprocal
                 const int mode = 4 * g + r;
-                if (mode < a.rep) a.out[node_of(a, t0.row, mode) * kC + 16 * wave + i] = fmaf(o[r], inv, ls * inv * bias);
+                if (mode < a.rep)
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, t0.row, mode) * 512u + out_lane)) =
+                        fmaf(o[r], inv, ls * inv * bias);
             }
         }
         if (tl[1].row < 0) return true;
-        // the next tile's DMA has landed (vmcnt) and this wave's LDS reads are done (lgkmcnt 0); a raw barrier:
+        // the DMAs of tile n + 2 have landed (vmcnt) and this wave's LDS reads are done (lgkmcnt 0); a raw barrier:
         // __syncthreads() would add a release fence, i.e. vmcnt(0)
-        __builtin_amdgcn_s_waitcnt(vmcnt_imm((kDepth - 1) * kOps) & ~0x0F00);
+        // (the four output stores of a row's last tile are younger than this iteration's loads and count as well)
+        if (last && a.rep >= 4) __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps + 4));
+        else __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps));
         __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int j = 0; j < 2 * kDepth; ++j) tl[j] = tl[j + 1];
-        tl[2 * kDepth] = tn;
+        for (int j = 0; j + 1 < kTiles; ++j) tl[j] = tl[j + 1];
+        tl[kTiles - 1] = tn;
         return false;
     };
     while (true) {
         if (step(std::integral_constant<int, 0>{})) break;
         if (step(std::integral_constant<int, 1>{})) break;
         if (step(std::integral_constant<int, 2>{})) break;
+        if (step(std::integral_constant<int, 3>{})) break;
+        if constexpr (kBufs > 4) if (step(std::integral_constant<int, 4 % kBufs>{})) break;
+        if constexpr (kBufs > 5) if (step(std::integral_constant<int, 5 % kBufs>{})) break;
     }
 }
 
@@ -386,7 +489,7 @@ extern "C" size_t qcn_attn_modes_pack_bytes(void) { return (size_t)kHeads * 2 * 
 extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v, const void *rhat_split,
                                   const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                                   const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
-                                  int rep, int layout, int64_t col_shift, float *out, void *stream)
+                                  int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream)
 {
     if (n_dst < 0 || n_src < 0 || n_rows < 0 || num_edges < 0 || rep < 1 || rep > 6) return QCN_ERR_INVALID_ARGUMENT;
     if (layout != 1 && layout != 2) return QCN_ERR_INVALID_ARGUMENT;
@@ -397,6 +500,10 @@ extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v
     if (n_dst >= ((int64_t)1 << 31) || n_src >= ((int64_t)1 << 31) || num_edges >= ((int64_t)1 << 31))
         return QCN_ERR_UNSUPPORTED;
     if (col_shift < 0 || col_shift >= ((int64_t)1 << 31)) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_feat_rows < 0 || (!eid && n_feat_rows < num_edges)) return QCN_ERR_INVALID_ARGUMENT;
+    // the kernel addresses q / out, k / v and rhat_split rows by 32-bit byte offsets (512 B per row)
+    const int64_t max_rows = (int64_t)1 << 23;
+    if (n_dst >= max_rows || n_src >= max_rows || n_feat_rows >= max_rows) return QCN_ERR_UNSUPPORTED;
     ModesArgs args{q, k, v, reinterpret_cast<const _Float16 *>(rhat_split), rowptr, col, eid,
                    reinterpret_cast<const half8 *>(wpack), bv, out, (int)n_rows, rep, layout, (int)col_shift};
     int per_cu = 2;

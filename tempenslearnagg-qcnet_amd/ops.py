@@ -574,6 +574,7 @@ def attn_modes(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat_split: to
     out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_attn_modes_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat_split), _ptr(rowptr), _ptr(col),
                                              _ptr(eid), _ptr(wpack), _ptr(bv), n_dst, n_src, n_rows, num_edges,
-                                             int(rep), int(layout), int(col_shift), _ptr(out), _stream(dev)),
+                                             rhat_split.size(0), int(rep), int(layout), int(col_shift), _ptr(out),
+                                             _stream(dev)),
                'qcn_attn_modes_f32')
     return out
