@@ -41,6 +41,11 @@ class NormalizedEdgeFeatures:
             self._split = ops.split_rows(self.rhat)
         return self._split
 
+    def prepare_for(self, rep: int) -> None:
+        """Convert ahead of the layers (on the preparation stream) what a relation with ``rep`` queries per row needs."""
+        if USE_ATTN_MODES and 1 < rep <= 6:
+            self.split  # noqa: B018  (cached property)
+
     @classmethod
     def from_raw(cls, r: torch.Tensor, eps: float = 1e-5) -> 'NormalizedEdgeFeatures':
         return cls(ops.row_normalize(r.contiguous(), eps))

@@ -16,6 +16,7 @@ from ..layers import AttentionLayer, FourierEmbedding, NormalizedEdgeFeatures
 from ..utils.geometry import angle_between_2d_vectors
 from ..utils.graph import CSRGraph, dense_to_sparse
 from ..utils.weight_init import weight_init
+from ..utils.prep import run_prep
 from ._common import node_ptr, rel_geometry
 
 
@@ -132,6 +133,11 @@ class QCNetAgentEncoder(nn.Module):
     # ------------------------------------------------------------------------------------------------------------
     @torch.no_grad()
     def precompute(self, data, first_shift: int, last_shift: int) -> Dict[str, object]:
+        """See :meth:`_precompute` (run on the preparation stream, utils/prep.py)."""
+        dev = data['agent']['position'].device
+        return run_prep(dev, lambda: self._precompute(data, first_shift, last_shift))
+
+    def _precompute(self, data, first_shift: int, last_shift: int) -> Dict[str, object]:
         """The sliding loop (predictors/temp_ens_learn_agg.py:197) encodes windows [ts, ts + T) for consecutive
         ``ts``.  A node (agent a, absolute step tau) has the same input features, the same spatial neighbours and the
         same relative geometry in every window that contains it (only the very first step of a window differs: its
@@ -270,35 +276,61 @@ class QCNetAgentEncoder(nn.Module):
         A, P = int(data['agent']['num_nodes']), int(data['map_polygon']['num_nodes'])
         F, n_abs = cache['n_frames'], cache['n_abs']
         dev = cache['x_main'].device
+        NA = A * n_abs
+        plan = run_prep(dev, lambda: self._stream_plan_graphs(cache, A, P, needed_from))
+        x_pl = map_enc['x_pl'][:, 0]
+        z = plan['z0']
+        for l in range(1, NL + 1):
+            L = plan['layers'][l - 1]
+            # input rows: [long run | the special destinations' own rows | special rows of the previous layer]; the
+            # first NA + n_own output rows are the ones that go on
+            inp = torch.cat([z[:NA], z[L['own_idx']], z[NA:]]) if L['n_own'] else z[:NA]
+            y = self.t_attn_layers[l - 1](inp, cache['r_t'], L['g_t'])
+            x2 = y[:NA + L['n_own']]
+            z = self.pl2a_attn_layers[l - 1]((x_pl, x2), cache['r_pl2a'], L['g_pl2a'])
+            z = self.a2a_attn_layers[l - 1](z, cache['r_a2a'], L['g_a2a'])
+        return z, plan['index']          # the last layer's output already is [long run | special rows]
+
+    def _stream_plan_graphs(self, cache, A: int, P: int, needed_from: int):
+        """The index work of :meth:`stream_frames` (depends on the validity masks only): per layer the temporal graph
+        over [long run | special destinations | previous special rows], the gather of the special destinations' own
+        rows and the spatial relations with their per-destination indirections; the layer-0 rows; the final index."""
+        T, C, S, NL = self.num_historical_steps, self.hidden_dim, self.time_span, self.num_layers
+        F, n_abs = cache['n_frames'], cache['n_abs']
+        dev = cache['x_main'].device
         D = self.streaming_plan(needed_from)
         if any(d > 0 for d in D[0]):
             raise AssertionError('layer-0 features differ from the long run at the first step only')
         NA = A * n_abs
-        x_pl = map_enc['x_pl'][:, 0]
         i64 = dict(device=dev, dtype=torch.int64)
         a_ids = torch.arange(A, **i64)
         frames = torch.arange(1, F, **i64)                                            # frames with special steps
 
         # long-run rows in time-major order (row u * A + a) through all layers: the spatial relations are time-major
         # anyway and the temporal edge list is simply numbered the same way, so nothing is ever transposed
-        xl = torch.cat([cache['x_first'][:, :1], cache['x_main'][:, 1:]], dim=1).transpose(0, 1).reshape(NA, C)
-        xs = cache['x_first'][:, 1:].transpose(0, 1).unsqueeze(1) if D[0] else None   # [F-1, |D0|, A, C]
+        xl0 = torch.cat([cache['x_first'][:, :1], cache['x_main'][:, 1:]], dim=1).transpose(0, 1).reshape(NA, C)
+        if D[0]:
+            z0 = torch.cat([xl0, cache['x_first'][:, 1:].transpose(0, 1).reshape(-1, C)])     # special rows (f, d = 0, a)
+        else:
+            z0 = xl0
         t_src, t_dst, t_agent = cache['t_src'], cache['t_dst'], cache['t_agent']
         E_abs = t_src.numel()
         can_src, can_dst = t_src * A + t_agent, t_dst * A + t_agent
+        layers = []
         for l in range(1, NL + 1):
             Dp, Dl = D[l - 1], D[l]
             n_prev, n_own = (F - 1) * len(Dp) * A, (F - 1) * len(Dl) * A
-            # input rows: [long run | the special destinations' own rows | special source rows of the previous layer];
-            # the first NA + n_own output rows are the ones that go on
-            parts = [xl]
             src_all, dst_all, eid_all = [can_src], [can_dst], [torch.arange(E_abs, **i64)]
+            own_idx = None
             if n_own:
                 # the destinations' own rows (residual / query input): previous-layer value at (f, d)
                 own = []
                 for d in Dl:
-                    own.append(xs[:, Dp.index(d)] if d in Dp else xl.view(n_abs, A, C)[frames + d])      # [F-1, A, C]
-                parts.append(torch.stack(own, dim=1).reshape(n_own, C))
+                    if d in Dp:
+                        own.append(NA + (((frames - 1) * len(Dp) + Dp.index(d)) * A).unsqueeze(1) + a_ids.unsqueeze(0))
+                    else:
+                        own.append(((frames + d) * A).unsqueeze(1) + a_ids.unsqueeze(0))                # [F-1, A]
+                own_idx = torch.stack(own, dim=1).reshape(n_own)
                 # their temporal edges: absolute edges into step f + d whose source lies inside frame f
                 d_vec = torch.tensor(Dl, **i64)
                 u_dst = (frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1)                          # [J]
@@ -316,17 +348,13 @@ class QCNetAgentEncoder(nn.Module):
                 src_all.append(torch.where(is_special, src_special, t_src[e_sel] * A + ag))
                 dst_all.append(NA + j_sel * A + ag)
                 eid_all.append(e_sel)
-                if n_prev:
-                    parts.append(xs.reshape(n_prev, C))
             n_in = NA + n_own + (n_prev if n_own else 0)
             g_t = CSRGraph.from_edge_index(torch.stack([torch.cat(src_all), torch.cat(dst_all)]), n_in, n_in,
                                            validate=False)
             g_t.eid = torch.cat(eid_all).to(torch.int32)[g_t.eid.long()]
             g_t.num_feature_rows = cache['r_t'].rhat.size(0)
-            y = self.t_attn_layers[l - 1](torch.cat(parts) if len(parts) > 1 else parts[0], cache['r_t'], g_t)
 
             # spatial relations over [long run | special rows (f, d, a)]
-            x2 = y[:NA + n_own]
             if n_own:
                 u_rows = ((frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1, 1) * A + a_ids.unsqueeze(0)).reshape(-1)
                 row_index = torch.cat([torch.arange(NA, **i64), u_rows])
@@ -336,10 +364,7 @@ class QCNetAgentEncoder(nn.Module):
                 g_a2a = cache['g_a2a'].with_rows(row_index, src_offset, NA + n_own)
             else:
                 g_pl2a, g_a2a = cache['g_pl2a'], cache['g_a2a']
-            z = self.pl2a_attn_layers[l - 1]((x_pl, x2), cache['r_pl2a'], g_pl2a)
-            z = self.a2a_attn_layers[l - 1](z, cache['r_a2a'], g_a2a)
-            xl = z[:NA]
-            xs = z[NA:].view(F - 1, len(Dl), A, C) if n_own else None
+            layers.append(dict(n_own=n_own, own_idx=own_idx, g_t=g_t, g_pl2a=g_pl2a, g_a2a=g_a2a))
 
         # every needed (frame, agent, step) as a row of ONE table: the long run's rows (u, a) followed by the special rows
         # of the last layer — consecutive frames share all but one of their steps, so the table has
@@ -349,7 +374,7 @@ class QCNetAgentEncoder(nn.Module):
         index = (steps.view(F, 1, -1) * A + a_ids.view(1, A, 1)).contiguous()                            # [F, A, Mt]
         for i, d in enumerate(D[NL]):
             index[1:, :, d - int(needed_from)] = NA + ((frames - 1).view(-1, 1) * len(D[NL]) + i) * A + a_ids.view(1, A)
-        return z, index          # the last layer's output already is [long run | special rows]
+        return dict(z0=z0, layers=layers, index=index)
 
     @torch.no_grad()
     def forward_frames_streaming(self, data, map_enc: Mapping[str, torch.Tensor], cache, needed_from: int) -> torch.Tensor:

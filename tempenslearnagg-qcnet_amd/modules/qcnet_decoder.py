@@ -15,6 +15,7 @@ from .. import ops
 from ..layers import AttentionLayer, FourierEmbedding, MLPLayer, NormalizedEdgeFeatures
 from ..utils.graph import CSRGraph, bipartite_dense_to_sparse, dense_to_sparse
 from ..utils.weight_init import weight_init
+from ..utils.prep import run_prep
 from ._common import node_ptr, rel_geometry
 
 
@@ -135,9 +136,7 @@ class QCNetDecoder(nn.Module):
         agent = data['agent']
         A = int(agent['num_nodes'])
         P = int(data['map_polygon']['num_nodes'])
-        pos_m = agent['position'][:, T - 1 + ts, :2].contiguous()
-        head_m = agent['heading'][:, T - 1 + ts].contiguous()
-        dev = pos_m.device
+        dev = agent['position'].device
 
         # only the last num_t2m_steps steps are ever sources of the time->mode attention (:143): project those alone.
         # A streamed encoding (QCNetAgentEncoder.stream_frames) comes as a table of distinct rows + an index per
@@ -155,47 +154,59 @@ class QCNetDecoder(nn.Module):
         x_pl = scene_enc['x_pl'][:, T - 1]          # [P, C]; reference tiles it K times (:150)
         x_a = x_a_now                               # [A, C]; reference tiles it K times (:151)
         m = self.mode_emb.weight.repeat(A, 1)
+        n_t_rows = x_t.size(0)
 
-        mask_src = agent['valid_mask'][:, ts:T + ts].clone()
-        mask_src[:, :T - self.num_t2m_steps] = False
-        mask_dst = agent['predict_mask'].any(dim=-1, keepdim=True).repeat(1, K)
+        def prepare():
+            """Masks, edge lists, CSR graphs and positional embeddings of the four relations: functions of ``data`` (and
+            of the index half of a streamed encoding) only — run on the preparation stream (utils/prep.py)."""
+            pos_m = agent['position'][:, T - 1 + ts, :2].contiguous()
+            head_m = agent['heading'][:, T - 1 + ts].contiguous()
+            mask_src = agent['valid_mask'][:, ts:T + ts].clone()
+            mask_src[:, :T - self.num_t2m_steps] = False
+            mask_dst = agent['predict_mask'].any(dim=-1, keepdim=True).repeat(1, K)
 
-        pos_t = agent['position'][:, ts:T + ts, :2].reshape(-1, 2)
-        head_t = agent['heading'][:, ts:T + ts].reshape(-1)
-        ei_t2m_1 = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst[:, -1:].unsqueeze(1))
-        r_t2m = rel_geometry(pos_t, pos_m, head_t, head_m, ei_t2m_1, extra=(ei_t2m_1[0] % T) - T + 1)
-        # One positional embedding / edge list per (step, agent) pair; the K mode queries of the agent share it
-        # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
-        r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=True))
-        ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
-        g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
-        col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
-        col = col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt)
-        if t_index is not None:
-            col = t_index.reshape(-1)[col]
-        g_t2m = g_t2m.remap_sources(col, x_t.size(0)).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
+            pos_t = agent['position'][:, ts:T + ts, :2].reshape(-1, 2)
+            head_t = agent['heading'][:, ts:T + ts].reshape(-1)
+            ei_t2m_1 = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst[:, -1:].unsqueeze(1))
+            r_t2m = rel_geometry(pos_t, pos_m, head_t, head_m, ei_t2m_1, extra=(ei_t2m_1[0] % T) - T + 1)
+            # One positional embedding / edge list per (step, agent) pair; the K mode queries of the agent share it
+            # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
+            r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=True))
+            ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
+            g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
+            col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
+            col = col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt)
+            if t_index is not None:
+                col = t_index.reshape(-1)[col]
+            g_t2m = g_t2m.remap_sources(col, n_t_rows).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
 
-        pos_pl = data['map_polygon']['position'][:, :2].contiguous()
-        orient_pl = data['map_polygon']['orientation'].contiguous()
-        ptr_a, ptr_p = node_ptr(data, 'agent', dev), node_ptr(data, 'map_polygon', dev)
-        dst_ok = mask_dst[:, 0].contiguous()
-        ei_pl2m_1, _ = ops.radius_pairs(pos_m, pos_pl, self.pl2m_radius, ptr_a, ptr_p, 300, mask_x=dst_ok)
-        r_pl2m = NormalizedEdgeFeatures(self.r_pl2m_emb(
-            continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=True))
-        ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
-        g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False).replicate(
-            K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_pl2m)
+            pos_pl = data['map_polygon']['position'][:, :2].contiguous()
+            orient_pl = data['map_polygon']['orientation'].contiguous()
+            ptr_a, ptr_p = node_ptr(data, 'agent', dev), node_ptr(data, 'map_polygon', dev)
+            dst_ok = mask_dst[:, 0].contiguous()
+            ei_pl2m_1, _ = ops.radius_pairs(pos_m, pos_pl, self.pl2m_radius, ptr_a, ptr_p, 300, mask_x=dst_ok)
+            r_pl2m = NormalizedEdgeFeatures(self.r_pl2m_emb(
+                continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=True))
+            ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
+            g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False).replicate(
+                K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_pl2m)
 
-        src_ok = mask_src[:, -1].contiguous()
-        ei_a2m_1, off_a2m = ops.radius_pairs(pos_m, pos_m, self.a2m_radius, ptr_a, ptr_a, 300 + 1, drop_self=True,
-                                             mask_x=src_ok, mask_y=dst_ok, y_first=False)
-        r_a2m = NormalizedEdgeFeatures(self.r_a2m_emb(
-            continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None, normalized_output=True))
-        ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
-        g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_a2m)
+            src_ok = mask_src[:, -1].contiguous()
+            ei_a2m_1, off_a2m = ops.radius_pairs(pos_m, pos_m, self.a2m_radius, ptr_a, ptr_a, 300 + 1, drop_self=True,
+                                                 mask_x=src_ok, mask_y=dst_ok, y_first=False)
+            r_a2m = NormalizedEdgeFeatures(self.r_a2m_emb(
+                continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None, normalized_output=True))
+            ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
+            g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_a2m)
 
-        ei_m2m = dense_to_sparse(mask_dst.unsqueeze(2) & mask_dst.unsqueeze(1))[0]
-        g_m2m = CSRGraph.from_edge_index(ei_m2m, A * K, A * K, validate=False)
+            ei_m2m = dense_to_sparse(mask_dst.unsqueeze(2) & mask_dst.unsqueeze(1))[0]
+            g_m2m = CSRGraph.from_edge_index(ei_m2m, A * K, A * K, validate=False)
+            for r in (r_t2m, r_pl2m, r_a2m):
+                r.prepare_for(K)
+            return (r_t2m, r_pl2m, r_a2m, g_t2m, g_pl2m, g_a2m, g_m2m, ei_pl2m_1, ei_t2m, ei_pl2m, ei_a2m, ei_m2m)
+
+        (r_t2m, r_pl2m, r_a2m, g_t2m, g_pl2m, g_a2m, g_m2m,
+         ei_pl2m_1, ei_t2m, ei_pl2m, ei_a2m, ei_m2m) = run_prep(dev, prepare)
 
         graphs = (x_t, x_pl, x_a, r_t2m, r_pl2m, r_a2m, g_t2m, g_pl2m, g_a2m, g_m2m)
         locs: List[torch.Tensor] = []

@@ -14,6 +14,7 @@ from .. import ops
 from ..layers import AttentionLayer, FourierEmbedding, NormalizedEdgeFeatures
 from ..utils.graph import CSRGraph, merge_edges
 from ..utils.weight_init import weight_init
+from ..utils.prep import run_prep
 from ._common import node_ptr, rel_geometry
 
 
@@ -57,36 +58,43 @@ class QCNetMapEncoder(nn.Module):
         self.apply(weight_init)
 
     def forward(self, data) -> Dict[str, torch.Tensor]:
-        pt, pl = data['map_point'], data['map_polygon']
-        pos_pt = pt['position'][:, :2].contiguous()
-        orient_pt = pt['orientation'].contiguous()
-        pos_pl = pl['position'][:, :2].contiguous()
-        orient_pl = pl['orientation'].contiguous()
-        n_pt, n_pl = pos_pt.size(0), pos_pl.size(0)
+        def prepare():
+            # everything that depends on the map alone: input embeddings, both relations with their positional
+            # embeddings (runs on the preparation stream, utils/prep.py)
+            pt, pl = data['map_point'], data['map_polygon']
+            pos_pt = pt['position'][:, :2].contiguous()
+            orient_pt = pt['orientation'].contiguous()
+            pos_pl = pl['position'][:, :2].contiguous()
+            orient_pl = pl['orientation'].contiguous()
+            n_pt, n_pl = pos_pt.size(0), pos_pl.size(0)
 
-        x_pt = self.x_pt_emb(continuous_inputs=pt['magnitude'].unsqueeze(-1),
-                             categorical_embs=[self.type_pt_emb(pt['type'].long()), self.side_pt_emb(pt['side'].long())])
-        x_pl = self.x_pl_emb(continuous_inputs=None,
-                             categorical_embs=[self.type_pl_emb(pl['type'].long()),
-                                               self.int_pl_emb(pl['is_intersection'].long())])
+            x_pt = self.x_pt_emb(continuous_inputs=pt['magnitude'].unsqueeze(-1),
+                                 categorical_embs=[self.type_pt_emb(pt['type'].long()), self.side_pt_emb(pt['side'].long())])
+            x_pl = self.x_pl_emb(continuous_inputs=None,
+                                 categorical_embs=[self.type_pl_emb(pl['type'].long()),
+                                                   self.int_pl_emb(pl['is_intersection'].long())])
 
-        ei_pt2pl = data['map_point', 'to', 'map_polygon']['edge_index']
-        g_pt2pl = CSRGraph.from_edge_index(ei_pt2pl, n_pt, n_pl)
-        r_pt2pl = NormalizedEdgeFeatures(self.r_pt2pl_emb(
-            continuous_inputs=rel_geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl), categorical_embs=None, normalized_output=True))
+            ei_pt2pl = data['map_point', 'to', 'map_polygon']['edge_index']
+            g_pt2pl = CSRGraph.from_edge_index(ei_pt2pl, n_pt, n_pl)
+            r_pt2pl = NormalizedEdgeFeatures(self.r_pt2pl_emb(
+                continuous_inputs=rel_geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl), categorical_embs=None, normalized_output=True))
 
-        ptr_pl = node_ptr(data, 'map_polygon', pos_pl.device)
-        ei_radius, _ = ops.radius_pairs(pos_pl, pos_pl, self.pl2pl_radius, ptr_pl, ptr_pl, 300 + 1, drop_self=True,
-                                        y_first=False)
-        type_data = data['map_polygon', 'to', 'map_polygon']['type']
-        ei_pl2pl, type_pl2pl = merge_edges(
-            edge_indices=[ei_radius, data['map_polygon', 'to', 'map_polygon']['edge_index']],
-            edge_attrs=[type_data.new_zeros(ei_radius.size(1), dtype=torch.uint8), type_data], reduce='max')
-        g_pl2pl = CSRGraph.from_edge_index(ei_pl2pl, n_pl, n_pl)
-        r_pl2pl = NormalizedEdgeFeatures(self.r_pl2pl_emb(
-            continuous_inputs=rel_geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl),
-            categorical_embs=[self.type_pl2pl_emb(type_pl2pl.long())], normalized_output=True))
+            ptr_pl = node_ptr(data, 'map_polygon', pos_pl.device)
+            ei_radius, _ = ops.radius_pairs(pos_pl, pos_pl, self.pl2pl_radius, ptr_pl, ptr_pl, 300 + 1, drop_self=True,
+                                            y_first=False)
+            type_data = data['map_polygon', 'to', 'map_polygon']['type']
+            ei_pl2pl, type_pl2pl = merge_edges(
+                edge_indices=[ei_radius, data['map_polygon', 'to', 'map_polygon']['edge_index']],
+                edge_attrs=[type_data.new_zeros(ei_radius.size(1), dtype=torch.uint8), type_data], reduce='max')
+            g_pl2pl = CSRGraph.from_edge_index(ei_pl2pl, n_pl, n_pl)
+            r_pl2pl = NormalizedEdgeFeatures(self.r_pl2pl_emb(
+                continuous_inputs=rel_geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl),
+                categorical_embs=[self.type_pl2pl_emb(type_pl2pl.long())], normalized_output=True))
 
+            return x_pt, x_pl, g_pt2pl, r_pt2pl, g_pl2pl, r_pl2pl, ei_pl2pl, type_pl2pl
+
+        x_pt, x_pl, g_pt2pl, r_pt2pl, g_pl2pl, r_pl2pl, ei_pl2pl, type_pl2pl = run_prep(
+            data['map_polygon']['position'].device, prepare)
         for i in range(self.num_layers):
             x_pl = self.pt2pl_layers[i]((x_pt, x_pl), r_pt2pl, g_pt2pl)
             x_pl = self.pl2pl_layers[i](x_pl, r_pl2pl, g_pl2pl)

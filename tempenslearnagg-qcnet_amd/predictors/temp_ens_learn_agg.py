@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..modules import TemporalAggregate
+from ..utils.prep import inputs_ready, run_prep
 from .qcnet_sliding import QCNetSliding
 
 
@@ -67,11 +68,13 @@ class TempEnsLearnAgg(nn.Module):
         T, n_f = self.num_historical_steps, self.num_frames
         enc, dec = self.base_model.encoder, self.base_model.decoder
         A = int(data['agent']['num_nodes'])
+        dev = data['agent']['position'].device
+        inputs_ready(dev)                       # the preparation stream (utils/prep.py) may read `data` from here on
         map_enc = enc.map_encoder(data)
         cache = enc.agent_encoder.precompute(data, 1, n_f)
         x_pl = map_enc['x_pl'][:, 0]
         x_pl_frames = x_pl.repeat(n_f, 1).unsqueeze(1).expand(-1, T, -1)
-        frames = frame_batch(data, 1, n_f, T + 2)
+        frames = run_prep(dev, lambda: frame_batch(data, 1, n_f, T + 2))
         if self.stream_encoder:
             Mt = min(dec.num_t2m_steps, T)
             table, index = enc.agent_encoder.stream_frames(data, map_enc, cache, T - Mt)           # [N, C], [F, A, Mt]
@@ -90,6 +93,7 @@ class TempEnsLearnAgg(nn.Module):
         """Ten sliding QCNet frames + learned aggregation (reference :196-221, :261)."""
         if self.batch_frames and self.share_map_encoding and self.share_frame_work:
             return self._predict_frames_batched(data)
+        inputs_ready(data['agent']['position'].device)
         map_enc = self.base_model.encoder.map_encoder(data) if self.share_map_encoding else None
         agent_cache = None
         if self.share_frame_work:

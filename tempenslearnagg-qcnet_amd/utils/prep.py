@@ -1,0 +1,80 @@
+"""Graph preparation on a second HIP stream.
+
+Everything a module derives from ``data`` alone — masks, radius searches, CSR builds, relative geometry, the positional
+Fourier embeddings — is a long chain of small launches with a few host round trips (``nonzero``, edge counts).  None of
+it depends on the learned node features, so ``run_prep`` executes such a section on a per-device side stream: its host
+round trips then wait for the side stream only, the host keeps enqueueing, and the small launches overlap the attention
+/ MLP kernels of the main stream (those of the previous module, or of the previous ``predict`` call).  The main stream
+waits for the section's event before it consumes the results.
+
+The reference has no counterpart (it runs one eager stream); with ``QCN_PREP_STREAM=0`` the sections run inline.
+"""
+import os
+from typing import Callable, Dict
+
+import torch
+
+ENABLED = os.environ.get('QCN_PREP_STREAM', '1') != '0'
+
+_side: Dict[int, 'torch.cuda.Stream'] = {}
+_depth = 0
+
+
+def side_stream(device: torch.device) -> 'torch.cuda.Stream':
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _side:
+        _side[idx] = torch.cuda.Stream(device=device)
+    return _side[idx]
+
+
+def _record(obj, stream, seen) -> None:
+    """Tell the caching allocator that every tensor reachable from ``obj`` is also used on ``stream``."""
+    if torch.is_tensor(obj):
+        if obj.is_cuda and obj.data_ptr() not in seen:
+            seen.add(obj.data_ptr())
+            obj.record_stream(stream)
+        return
+    if obj is None or isinstance(obj, (int, float, str, bool)):
+        return
+    if id(obj) in seen:
+        return
+    seen.add(id(obj))
+    if isinstance(obj, dict):
+        for v in obj.values():
+            _record(v, stream, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record(v, stream, seen)
+    else:
+        for name in getattr(type(obj), '__slots__', ()):
+            _record(getattr(obj, name, None), stream, seen)
+        if hasattr(obj, '__dict__'):
+            for v in vars(obj).values():
+                _record(v, stream, seen)
+
+
+def inputs_ready(device: torch.device) -> None:
+    """Order the side stream after everything enqueued on the current stream so far (call once where fresh inputs
+    enter, e.g. at the top of ``predict``): sections started later may read those inputs."""
+    if ENABLED and device.type == 'cuda':
+        side_stream(device).wait_stream(torch.cuda.current_stream(device))
+
+
+def run_prep(device: torch.device, fn: Callable[[], object]):
+    """Run ``fn`` (which must depend on ``data`` and on results of earlier sections only) on the side stream and make
+    the current stream wait for it; returns ``fn()``.  Nested sections run inline in the enclosing one."""
+    global _depth
+    if not ENABLED or _depth > 0 or device.type != 'cuda':
+        return fn()
+    main = torch.cuda.current_stream(device)
+    side = side_stream(device)
+    _depth += 1
+    try:
+        with torch.cuda.stream(side):
+            out = fn()
+            done = side.record_event()
+    finally:
+        _depth -= 1
+    _record(out, main, set())
+    main.wait_event(done)
+    return out
