@@ -175,7 +175,8 @@ int qcn_get_matmul_mode(void);
  *   categorical embeddings, row n of the output uses extra row n / extra_div (modules/qcnet_agent_encoder.py:109
  *   repeats one type embedding per agent over T steps: extra_div = T); y [n_rows, 128].
  *   normalize_out != 0 additionally applies (y - mean) / sqrt(var + 1e-5) per row, the layer-independent half of the
- *   consuming AttentionLayers' attn_prenorm_r (layers/attention_layer.py:82).
+ *   consuming AttentionLayers' attn_prenorm_r (layers/attention_layer.py:82); normalize_out == 2 writes that result
+ *   as split-f16 rows instead (y = [n_rows, 256] f16, scale 2^11: the rhat_split operand of qcn_attn_modes_f32).
  *   pack: qcn_fourier_pack_floats(input_dim) floats: the 2 input_dim + 1 chain-packed matrices
  *     [mlps.0.0.weight[:, :128] (cos | sin order above), mlps.0.3.weight, mlps.1.0.weight[:, :128], ..., to_out.2.weight]
  *   then per input dim i

@@ -223,6 +223,28 @@ __device__ __forceinline__ void store_row(const f32x16 (&v)[4], float *__restric
         }
 }
 
+// The row as split f16 (the operand format of qcn_attn_modes_f32, see qcn_split_rows_f16): dst row = [hi 128 | lo 128]
+// with hi + lo = v * scale
+__device__ __forceinline__ void store_row_split(const f32x16 (&v)[4], _Float16 *__restrict__ dst, int64_t row, int h, float scale)
+{
+    using half4v = __attribute__((ext_vector_type(4))) _Float16;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            half4v hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = v[t][4 * q + j] * scale;
+                hi[j] = (_Float16)a;
+                lo[j] = (_Float16)(a - (float)hi[j]);
+            }
+            _Float16 *p = dst + row * (2 * kC) + 32 * t + 8 * q + 4 * h;
+            *reinterpret_cast<half4v *>(p) = hi;
+            *reinterpret_cast<half4v *>(p + kC) = lo;
+        }
+}
+
 // LayerNorm over the 128 features of the lane's row (two-pass mean / variance), optional affine and ReLU
 template <bool AFFINE, bool RELU>
 __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restrict__ gamma,

@@ -141,7 +141,10 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
     if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
     if (tail.n_out == 0) {
-        if (valid) store_row(acc_o, y, row, h);
+        if (valid) {
+            if (normalize_out == 2) store_row_split(acc_o, reinterpret_cast<_Float16 *>(y), row, h, 2048.0f);
+            else store_row(acc_o, y, row, h);
+        }
         return;
     }
     // ---- tail: the embedding is the operand of n_out more layers (matrix j sits in buffer (j + 1) & 1)

@@ -30,8 +30,14 @@ class NormalizedEdgeFeatures:
     __slots__ = ('rhat', '_split')
 
     def __init__(self, rhat: torch.Tensor) -> None:
-        self.rhat = rhat
-        self._split = None
+        if rhat.dtype == torch.float16:      # already in the split operand format (FourierEmbedding normalized_output='split')
+            self.rhat, self._split = None, rhat
+        else:
+            self.rhat, self._split = rhat, None
+
+    @property
+    def num_rows(self) -> int:
+        return int((self.rhat if self.rhat is not None else self._split).size(0))
 
     @property
     def split(self) -> torch.Tensor:
@@ -40,6 +46,14 @@ class NormalizedEdgeFeatures:
         if self._split is None:
             self._split = ops.split_rows(self.rhat)
         return self._split
+
+    @property
+    def dense(self) -> torch.Tensor:
+        """fp32 rows [E_base, 128] (the operand of qcn_attn_fused_f32)."""
+        if self.rhat is None:
+            sp = self._split.float()
+            self.rhat = ((sp[:, :ops.C] + sp[:, ops.C:]) * 2.0 ** -ops.RHAT_SPLIT_SCALE_LOG2).contiguous()
+        return self.rhat
 
     def prepare_for(self, rep: int) -> None:
         """Convert ahead of the layers (on the preparation stream) what a relation with ``rep`` queries per row needs."""
@@ -165,8 +179,8 @@ class AttentionLayer(nn.Module):
         if self.has_pos_emb and r is not None:
             if not isinstance(r, NormalizedEdgeFeatures):
                 r = NormalizedEdgeFeatures.from_raw(r, self.attn_prenorm_r.eps)
-            if r.rhat.size(0) != graph.num_feature_rows:
-                raise ValueError('r has %d rows for %d edges' % (r.rhat.size(0), graph.num_feature_rows))
+            if r.num_rows != graph.num_feature_rows:
+                raise ValueError('r has %d rows for %d edges' % (r.num_rows, graph.num_feature_rows))
         else:
             r = None
         # pre: LayerNorm + q/k/v/s projections (one or two launches)
@@ -185,7 +199,7 @@ class AttentionLayer(nn.Module):
                 agg = ops.attn_modes(q, k, v, r.split, graph.rowptr, graph.col, graph.eid, packs['pos_modes'], bv,
                                      graph.rep, graph.layout, graph.col_shift)
             else:
-                agg = ops.attn_fused(q, k, v, r.rhat, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep,
+                agg = ops.attn_fused(q, k, v, r.dense, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep,
                                      graph.layout,
                                      graph.col_shift, graph.row_index, graph.src_offset)
         else:

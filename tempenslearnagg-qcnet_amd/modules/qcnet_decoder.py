@@ -12,6 +12,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from ..layers import attention_layer
 from ..layers import AttentionLayer, FourierEmbedding, MLPLayer, NormalizedEdgeFeatures
 from ..utils.graph import CSRGraph, bipartite_dense_to_sparse, dense_to_sparse
 from ..utils.weight_init import weight_init
@@ -161,6 +162,8 @@ class QCNetDecoder(nn.Module):
             of the index half of a streamed encoding) only — run on the preparation stream (utils/prep.py)."""
             pos_m = agent['position'][:, T - 1 + ts, :2].contiguous()
             head_m = agent['heading'][:, T - 1 + ts].contiguous()
+            # the three mode relations are consumed by qcn_attn_modes_f32 only: embeddings straight in its operand format
+            r_fmt = 'split' if (attention_layer.USE_ATTN_MODES and 1 < K <= 6) else True
             mask_src = agent['valid_mask'][:, ts:T + ts].clone()
             mask_src[:, :T - self.num_t2m_steps] = False
             mask_dst = agent['predict_mask'].any(dim=-1, keepdim=True).repeat(1, K)
@@ -171,7 +174,7 @@ class QCNetDecoder(nn.Module):
             r_t2m = rel_geometry(pos_t, pos_m, head_t, head_m, ei_t2m_1, extra=(ei_t2m_1[0] % T) - T + 1)
             # One positional embedding / edge list per (step, agent) pair; the K mode queries of the agent share it
             # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
-            r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=True))
+            r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=r_fmt))
             ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
             g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
             col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
@@ -186,7 +189,7 @@ class QCNetDecoder(nn.Module):
             dst_ok = mask_dst[:, 0].contiguous()
             ei_pl2m_1, _ = ops.radius_pairs(pos_m, pos_pl, self.pl2m_radius, ptr_a, ptr_p, 300, mask_x=dst_ok)
             r_pl2m = NormalizedEdgeFeatures(self.r_pl2m_emb(
-                continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=True))
+                continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=r_fmt))
             ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
             g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False).replicate(
                 K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_pl2m)
@@ -195,7 +198,7 @@ class QCNetDecoder(nn.Module):
             ei_a2m_1, off_a2m = ops.radius_pairs(pos_m, pos_m, self.a2m_radius, ptr_a, ptr_a, 300 + 1, drop_self=True,
                                                  mask_x=src_ok, mask_y=dst_ok, y_first=False)
             r_a2m = NormalizedEdgeFeatures(self.r_a2m_emb(
-                continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None, normalized_output=True))
+                continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None, normalized_output=r_fmt))
             ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
             g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_a2m)
 

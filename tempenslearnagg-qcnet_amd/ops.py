@@ -249,10 +249,14 @@ def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor,
         _require(extra, 'categorical embedding sum', torch.float32, dev, ((n_rows + extra_div - 1) // extra_div, C))
     elif input_dim == 0:
         raise ValueError('Both continuous_inputs and categorical_embs are None')
-    y = torch.empty(n_rows, C, dtype=torch.float32, device=dev)
+    split = normalize_out == 'split'        # row-normalised AND in the split-f16 operand format of attn_modes
+    if split:
+        y = torch.empty(n_rows, 2 * C, dtype=torch.float16, device=dev)
+    else:
+        y = torch.empty(n_rows, C, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_fourier_embed_f32(_ptr(x) if input_dim > 0 else None, int(input_dim), _ptr(extra),
-                                                int(extra_div), _ptr(pack), n_rows, int(bool(normalize_out)), _ptr(y),
-                                                _stream(dev)), 'qcn_fourier_embed_f32')
+                                                int(extra_div), _ptr(pack), n_rows, 2 if split else int(bool(normalize_out)),
+                                                _ptr(y), _stream(dev)), 'qcn_fourier_embed_f32')
     return y
 
 

@@ -31,6 +31,22 @@ def test_fourier_embedding_vs_reference_golden(tag):
     assert rel_err(got, torch.from_numpy(g[tag + '.out'])) < TOL
 
 
+def test_fourier_embedding_split_output_is_the_split_of_the_normalised_output():
+    """normalized_output='split' (qcn_fourier_embed_f32 normalize_out = 2) == qcn_split_rows_f16 of the row-normalised
+    fp32 output, bit for bit, and hi + lo reproduces it to 2^-21 relative."""
+    from tempenslearnagg_qcnet_amd import ops
+    torch.manual_seed(3)
+    m = randomize_(FourierEmbedding(input_dim=3, hidden_dim=128, num_freq_bands=64), seed=4).eval().to(DEV)
+    x = torch.randn(777, 3, device=DEV) * torch.tensor([30.0, 3.0, 3.0], device=DEV)
+    with torch.no_grad():
+        dense = m(continuous_inputs=x, categorical_embs=None, normalized_output=True)
+        split = m(continuous_inputs=x, categorical_embs=None, normalized_output='split')
+    assert split.dtype == torch.float16 and tuple(split.shape) == (777, 256)
+    assert torch.equal(split, ops.split_rows(dense))
+    back = (split[:, :128].double() + split[:, 128:].double()) / 2048.0
+    assert float((back - dense.double()).abs().max()) <= 2.0 ** -21 * float(dense.abs().max())
+
+
 @pytest.mark.parametrize('out_dim', [1, 40, 120])
 def test_mlp_layer_vs_reference_golden(out_dim):
     g = load_golden('ref_layers.npz')
