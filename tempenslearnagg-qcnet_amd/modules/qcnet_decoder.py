@@ -5,6 +5,7 @@ The propose/refine stacks run on destination-sorted CSR graphs built once per ca
 polygon and agent features (reference :150-151) is folded away: sources are gathered from the single copy.
 ``TemporalAggregate`` shares this implementation through the ``_fuse_modes`` hook.
 """
+import os
 from typing import Dict, List, Mapping, Optional
 
 import torch
@@ -163,7 +164,7 @@ class QCNetDecoder(nn.Module):
             pos_m = agent['position'][:, T - 1 + ts, :2].contiguous()
             head_m = agent['heading'][:, T - 1 + ts].contiguous()
             # the three mode relations are consumed by qcn_attn_modes_f32 only: embeddings straight in its operand format
-            r_fmt = 'split' if (attention_layer.USE_ATTN_MODES and 1 < K <= 6) else True
+            r_fmt = 'split' if (attention_layer.USE_ATTN_MODES and 1 < K <= 6 and os.environ.get('QCN_R_SPLIT_FUSED', '1') != '0') else True
             mask_src = agent['valid_mask'][:, ts:T + ts].clone()
             mask_src[:, :T - self.num_t2m_steps] = False
             mask_dst = agent['predict_mask'].any(dim=-1, keepdim=True).repeat(1, K)
