@@ -24,6 +24,7 @@
 // per destination (q in, out) — the same figure as qcn_attn_fused_f32.
 #include "common.hip.h"
 #include <cstdlib>
+#include <cstdio>
 #include <type_traits>
 
 namespace {
@@ -78,6 +79,7 @@ struct ModesArgs {
     const float *bv;
     float *out;
     int n_rows, rep, layout, col_shift;
+    unsigned long long *stamps;    // QCN_MODES_STAMPS builds only
 };
 
 // one 16-edge tile of one CSR row: edges [j0, j0 + 16) clipped to `end`
@@ -354,6 +356,12 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 
     f32x4 qa = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f}, kk, vv;
     float m[4], l[4];
+#ifdef QCN_MODES_STAMPS
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_it = 0;
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_t[k] += now_ - last_; last_ = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define STAMP(k)
+#endif
     project(&s_0, kk, vv, [](int) {});
 
     // one iteration with the current tile in ring slot S; returns true after the last tile
@@ -362,11 +370,18 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         constexpr int SN = (S + 1) % kBufs;                    // slot of the next tile (projected now)
         constexpr int SB = (S + kDepth) % kBufs;               // slot of the tile kDepth ahead (DMAs + q now)
         constexpr int SC = (S + kDepth + kIdxAhead) % kBufs;   // slot of the indices loaded now
+#ifdef QCN_MODES_STAMPS
+        unsigned long long last_ = __builtin_amdgcn_s_memtime();
+        ++n_it;
+#endif
         const Tile t0 = tl[0], tb = safe(tl[kDepth]), tc = safe(tl[kTiles - 1]);
         const Tile tn = next_tile(a, tl[kTiles - 1], row_end);
+        STAMP(0)
         issue_tile_dma(a, idx[SB], slot_of(std::integral_constant<int, SB>{}), wave, lane);
+        STAMP(1)
         qring[SB] = load_q(a, tb.row, wave, lane);
         idx[SC] = load_tile_idx<HAS_EID>(a, tc, wave, lane);
+        STAMP(2)
 
         if (t0.first) {
             qa = qring[S] * (0.25f * kLog2e);     // head_dim ** -0.5 (layers/attention_layer.py:38), logits in base 2
@@ -418,6 +433,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         o += o2;
         kk = kk_n;
         vv = vv_n;
+        STAMP(3)
 
         const bool last = tl[1].row != t0.row;                  // last tile of its row
         if (last) {
@@ -433,13 +449,16 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
                         fmaf(o[r], inv, ls * inv * bias);
             }
         }
+        STAMP(4)
         if (tl[1].row < 0) return true;
         // the DMAs of tile n + 2 have landed (vmcnt) and this wave's LDS reads are done (lgkmcnt 0); a raw barrier:
         // __syncthreads() would add a release fence, i.e. vmcnt(0)
         // (the four output stores of a row's last tile are younger than this iteration's loads and count as well)
         if (last && a.rep >= 4) __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps + 4));
         else __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps));
+        STAMP(5)
         __builtin_amdgcn_s_barrier();
+        STAMP(6)
 #pragma unroll
         for (int j = 0; j + 1 < kTiles; ++j) tl[j] = tl[j + 1];
         tl[kTiles - 1] = tn;
@@ -452,6 +471,170 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         if (step(std::integral_constant<int, 3>{})) break;
         if constexpr (kBufs > 4) if (step(std::integral_constant<int, 4 % kBufs>{})) break;
         if constexpr (kBufs > 5) if (step(std::integral_constant<int, 5 % kBufs>{})) break;
+    }
+#ifdef QCN_MODES_STAMPS
+    if (blockIdx.x == 0 && lane == 0 && a.stamps) {
+        for (int k = 0; k < 7; ++k) a.stamps[wave * 8 + k] = acc_t[k];
+        a.stamps[wave * 8 + 7] = n_it;
+    }
+#endif
+}
+
+// Lean variant: two ring slots, no projection-ahead, at most 128 registers — two workgroups per CU, so that one
+// workgroup's DMA wait / barrier / row epilogue overlaps the other one's MFMA phase (the pipelined kernel above keeps
+// one workgroup per CU and hides latency inside the workgroup instead).
+template <bool HAS_EID>
+__global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesArgs a)
+{
+    __shared__ __attribute__((aligned(16))) Slot s_0;
+    __shared__ __attribute__((aligned(16))) Slot s_1;
+    __shared__ __attribute__((aligned(16))) float s_t[kHeads][16 * kTStride];
+    constexpr int kLate = HAS_EID ? 2 : 1;                // loads issued after the DMAs in an iteration: the indices (+ q)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+
+    const int nb = gridDim.x;
+    const int lb = qcn_xcd_remap(blockIdx.x, gridDim.x);
+    const int per = (a.n_rows + nb - 1) / nb;
+    const int row_begin = min(lb * per, a.n_rows), row_end = min(row_begin + per, a.n_rows);
+
+    half8 wk_hi[4], wk_lo[4], wv_hi[4], wv_lo[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const half8 *base = a.wfrag + (size_t)((wave * 2) * 4 + ks) * 2 * 64 + lane;
+        wk_hi[ks] = base[0];
+        wk_lo[ks] = base[64];
+        wv_hi[ks] = base[4 * 2 * 64];
+        wv_lo[ks] = base[4 * 2 * 64 + 64];
+    }
+    const float *scales = reinterpret_cast<const float *>(a.wfrag + (size_t)kHeads * 2 * 4 * 2 * 64);
+    const float usc_k = scales[0], usc_v = scales[1];
+    const float bias = a.bv[16 * wave + i];
+    float *const s_tw = s_t[wave];
+    const uint32_t out_lane = 64u * wave + 4u * i;
+    const int r_base = i * kRowBytes, r_x = 16 * i;       // rhat chunk of k-step ks: r_base + ((64 ks + 16 g) ^ r_x)
+    const int k_off = i * kRowBytes + 16 * ((4 * wave + g) ^ i);
+    const int v_base = 4 * g * kRowBytes + 4 * (i & 3), v_c = 4 * wave + (i >> 2);
+
+    for (int row = row_begin; row < row_end; ++row) {
+        if (rowptr_at(a, row + 1) > rowptr_at(a, row)) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mode = 4 * g + r;
+            if (mode < a.rep) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, row, mode) * 512u + out_lane)) = 0.f;
+        }
+    }
+
+    Tile t0 = first_tile(a, row_begin, row_end);
+    if (t0.row < 0) return;
+    Tile t1 = next_tile(a, t0, row_end), t2 = next_tile(a, t1, row_end);
+    auto safe = [&](const Tile &t) -> Tile { return t.row >= 0 ? t : t0; };
+    TileIdx x1;
+    {
+        const TileIdx x0 = load_tile_idx<HAS_EID>(a, t0, wave, lane);
+        issue_tile_dma(a, x0, &s_0, wave, lane);
+        x1 = load_tile_idx<HAS_EID>(a, safe(t1), wave, lane);
+    }
+    __builtin_amdgcn_s_waitcnt(wait_imm(0));
+    __builtin_amdgcn_s_barrier();
+
+    f32x4 qa = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+    float m[4], l[4];
+
+    auto step = [&](auto ph) -> bool {
+        constexpr int S = decltype(ph)::value;
+        Slot *const cur = S == 0 ? &s_0 : &s_1;
+        Slot *const nxt = S == 0 ? &s_1 : &s_0;
+        const Tile tn = next_tile(a, t2, row_end);
+        // DMAs of the next tile first, then the loads that may stay in flight over the barrier
+        issue_tile_dma(a, x1, nxt, wave, lane);
+        x1 = load_tile_idx<HAS_EID>(a, safe(t2), wave, lane);
+
+        const bool first = t0.first;
+        if (first) {                    // q is used after the projection MFMAs: its latency hides behind them
+            qa = load_q(a, t0.row, wave, lane) * (0.25f * kLog2e);
+            if (i >= a.rep) qa = f32x4{0.f, 0.f, 0.f, 0.f};
+            o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+        }
+        // the small products first: the accumulator then grows the way a sorted sum does
+        f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int off = r_base + ((64 * ks + 16 * g) ^ r_x);
+            const half8 rh = *reinterpret_cast<const half8 *>(cur->r + off);
+            const half8 rl = *reinterpret_cast<const half8 *>(cur->r + off + 256);
+            kk = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_hi[ks], rl, kk, 0, 0, 0);
+            vv = __builtin_amdgcn_mfma_f32_16x16x32_f16(rl, wv_hi[ks], vv, 0, 0, 0);
+            kk = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_lo[ks], rh, kk, 0, 0, 0);
+            vv = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh, wv_lo[ks], vv, 0, 0, 0);
+            kk = __builtin_amdgcn_mfma_f32_16x16x32_f16(wk_hi[ks], rh, kk, 0, 0, 0);
+            vv = __builtin_amdgcn_mfma_f32_16x16x32_f16(rh, wv_hi[ks], vv, 0, 0, 0);
+        }
+        const f32x4 kf = *reinterpret_cast<const f32x4 *>(cur->k + k_off);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float vf = *reinterpret_cast<const float *>(cur->v + v_base + r * kRowBytes + 16 * (v_c ^ (4 * g + r)));
+            kk[r] = fmaf(kk[r], usc_k, kf[r]);
+            vv[r] = fmaf(vv[r], usc_v, vf);
+        }
+        f32x4 p = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[r], kk[r], p, 0, 0, 0);
+        const bool valid = t0.j0 + i < t0.end;
+        float pv[4], mx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pv[r] = valid ? p[r] : -INFINITY; mx[r] = pv[r]; }
+        row16_max4(mx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mn = fmaxf(m[r], mx[r]);
+            const float corr = __builtin_amdgcn_exp2f(m[r] - mn);
+            m[r] = mn;
+            const float pe = __builtin_amdgcn_exp2f(pv[r] - mn);
+            l[r] = fmaf(l[r], corr, pe);
+            o[r] *= corr;
+            s_tw[(4 * g + r) * kTStride + i] = pe;
+        }
+        wave_lds_fence();
+        const f32x4 pa = *reinterpret_cast<const f32x4 *>(s_tw + i * kTStride + 4 * g);
+        wave_lds_fence();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[r], vv[r], o, 0, 0, 0);
+
+        const bool last = t1.row != t0.row;
+        if (last) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float ls = row16_sum(l[r]);
+                const float den = ls + 1e-16f;
+                float inv = __builtin_amdgcn_rcpf(den);
+                inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);
+                const int mode = 4 * g + r;
+                if (mode < a.rep)
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, t0.row, mode) * 512u + out_lane)) =
+                        fmaf(o[r], inv, ls * inv * bias);
+            }
+        }
+        if (t1.row < 0) return true;
+        // everything older than this iteration's late loads (indices, q of a first tile, output stores of a last tile)
+        // has landed: the next tile's DMAs
+        const int late = (first ? 1 : 0) + (last && a.rep >= 4 ? 4 : 0);
+        if (late == 0) __builtin_amdgcn_s_waitcnt(wait_imm(kLate));
+        else if (late == 1) __builtin_amdgcn_s_waitcnt(wait_imm(kLate + 1));
+        else if (late == 4) __builtin_amdgcn_s_waitcnt(wait_imm(kLate + 4));
+        else __builtin_amdgcn_s_waitcnt(wait_imm(kLate + 5));
+        __builtin_amdgcn_s_barrier();
+        t0 = t1; t1 = t2; t2 = tn;
+        return false;
+    };
+    while (true) {
+        if (step(std::integral_constant<int, 0>{})) break;
+        if (step(std::integral_constant<int, 1>{})) break;
     }
 }
 
@@ -505,15 +688,41 @@ extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v
     const int64_t max_rows = (int64_t)1 << 23;
     if (n_dst >= max_rows || n_src >= max_rows || n_feat_rows >= max_rows) return QCN_ERR_UNSUPPORTED;
     ModesArgs args{q, k, v, reinterpret_cast<const _Float16 *>(rhat_split), rowptr, col, eid,
-                   reinterpret_cast<const half8 *>(wpack), bv, out, (int)n_rows, rep, layout, (int)col_shift};
+                   reinterpret_cast<const half8 *>(wpack), bv, out, (int)n_rows, rep, layout, (int)col_shift, nullptr};
+#ifdef QCN_MODES_STAMPS
+    static unsigned long long *d_stamps = nullptr;
+    if (!d_stamps) (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long));
+    (void)hipMemsetAsync(d_stamps, 0, 64 * sizeof(unsigned long long), qcn_stream(stream));
+    args.stamps = d_stamps;
+#endif
     int per_cu = 2;
     if (const char *env = getenv("QCN_MODES_WG_PER_CU")) { const int want = atoi(env); if (want >= 1 && want <= 8) per_cu = want; }
     int64_t grid = n_rows < 256 * per_cu ? n_rows : 256 * per_cu;
     hipStream_t s = qcn_stream(stream);
     void *token = qcn_prof_begin(QCN_PROF_ATTN_FUSED, 1552.0 * (double)num_edges * (double)rep + 1024.0 * (double)n_dst, s);
-    if (eid) hipLaunchKernelGGL((attn_modes_kernel<true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
-    else     hipLaunchKernelGGL((attn_modes_kernel<false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+    // QCN_MODES_LEAN=1: the two-workgroups-per-CU variant (same results; measured equal on cfg3, kept for A/B runs)
+    const char *lean_env = getenv("QCN_MODES_LEAN");
+    const bool lean = lean_env && atoi(lean_env) != 0;
+    if (lean) {
+        if (eid) hipLaunchKernelGGL((attn_modes_lean_kernel<true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+        else     hipLaunchKernelGGL((attn_modes_lean_kernel<false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+    } else {
+        if (eid) hipLaunchKernelGGL((attn_modes_kernel<true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+        else     hipLaunchKernelGGL((attn_modes_kernel<false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+    }
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
+#ifdef QCN_MODES_STAMPS
+    {
+        unsigned long long h[64];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(h, d_stamps, sizeof(h), hipMemcpyDeviceToHost);
+        for (int w = 0; w < 8; w += 7) {
+            const double n = (double)h[w * 8 + 7];
+            if (n > 0) printf("stamps wave %d iters %.0f: next_tile %.0f dma %.0f loads %.0f compute %.0f store %.0f wait %.0f barrier %.0f cycles per iteration\n",
+                              w, n, h[w * 8] / n, h[w * 8 + 1] / n, h[w * 8 + 2] / n, h[w * 8 + 3] / n, h[w * 8 + 4] / n, h[w * 8 + 5] / n, h[w * 8 + 6] / n);
+        }
+    }
+#endif
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }

@@ -216,7 +216,13 @@ def _modes(q, k, v, r, graph, w_kr, w_vr, b_vr, gamma, beta, rep, layout):
     (2, 4, 64, 20, 700, None, None),
     (2, 6, 5, 9, 0, None, None),
 ])
-def test_attn_modes_vs_fp64_oracle(layout, K, n_rows, n_src, E, heavy, empty_from):
+@pytest.mark.parametrize('lean', ['0', '1'])
+def test_attn_modes_vs_fp64_oracle(layout, K, n_rows, n_src, E, heavy, empty_from, lean, monkeypatch):
+    monkeypatch.setenv('QCN_MODES_LEAN', lean)       # both kernel variants (pipelined one-per-CU, lean two-per-CU)
+    _attn_modes_case(layout, K, n_rows, n_src, E, heavy, empty_from)
+
+
+def _attn_modes_case(layout, K, n_rows, n_src, E, heavy, empty_from):
     """qcn_attn_modes_f32 (mode-replicated relations on the matrix cores) against the fp64 oracle on the explicitly
     K-times replicated graph, and against qcn_attn_fused_f32 on the same inputs.  Tolerance 2e-5 relative."""
     base = _graph(n_src, n_rows, E, 43, heavy=heavy, empty_from=empty_from)
