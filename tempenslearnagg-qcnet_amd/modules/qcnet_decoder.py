@@ -154,6 +154,10 @@ class QCNetDecoder(nn.Module):
             x_t = scene_enc['x_a'][:, T - Mt:].reshape(-1, C)
             x_a_now = scene_enc['x_a'][:, -1]
         x_pl = scene_enc['x_pl'][:, T - 1]          # [P, C]; reference tiles it K times (:150)
+        # a frame batch replicates the map per frame: the encoding may come as ONE copy ([P / F, C]), sources are folded
+        n_pl_rows = x_pl.size(0)
+        if n_pl_rows != P and (n_pl_rows == 0 or P % n_pl_rows != 0):
+            raise ValueError('x_pl has %d rows for %d polygons' % (n_pl_rows, P))
         x_a = x_a_now                               # [A, C]; reference tiles it K times (:151)
         m = self.mode_emb.weight.repeat(A, 1)
         n_t_rows = x_t.size(0)
@@ -192,8 +196,10 @@ class QCNetDecoder(nn.Module):
             r_pl2m = NormalizedEdgeFeatures(self.r_pl2m_emb(
                 continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=r_fmt))
             ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
-            g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False).replicate(
-                K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_pl2m)
+            g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False)
+            if n_pl_rows != P:
+                g_pl2m = g_pl2m.fold_sources(n_pl_rows)
+            g_pl2m = g_pl2m.replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_pl2m)
 
             src_ok = mask_src[:, -1].contiguous()
             ei_a2m_1, off_a2m = ops.radius_pairs(pos_m, pos_m, self.a2m_radius, ptr_a, ptr_a, 300 + 1, drop_self=True,

@@ -72,8 +72,8 @@ class TempEnsLearnAgg(nn.Module):
         inputs_ready(dev)                       # the preparation stream (utils/prep.py) may read `data` from here on
         map_enc = enc.map_encoder(data)
         cache = enc.agent_encoder.precompute(data, 1, n_f)
-        x_pl = map_enc['x_pl'][:, 0]
-        x_pl_frames = x_pl.repeat(n_f, 1).unsqueeze(1).expand(-1, T, -1)
+        # the frame batch replicates the map per frame; the decoder folds the polygon sources onto this one copy
+        x_pl_frames = map_enc['x_pl']
         frames = run_prep(dev, lambda: frame_batch(data, 1, n_f, T + 2))
         if self.stream_encoder:
             Mt = min(dec.num_t2m_steps, T)
