@@ -135,7 +135,7 @@ def main() -> None:
     # on a known byte count in the kernel's own access width: scripts/pmc_workload.py, scripts/pmc_summary.py); the
     # counters cannot be read from inside this process, so the committed summary of the same workload is quoted.
     traffic = None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_z_pmc_attn_fused.json')
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_final_pmc_attention.json')
     if args.config == 'cfg3' and batch_size == cfg['batch'] and os.path.exists(pmc_file):
         with open(pmc_file) as fh:
             traffic = json.load(fh)['attn_fused']['traffic_bytes_per_launch']
@@ -155,12 +155,12 @@ def main() -> None:
                        'global_batch': world * batch_size, 'parallelism': 'scenario-sharded x%d' % world,
                        'matmul': 'split-f16 x3 MFMA, 22-bit operands, fp32 accumulate (backward error 8.7e-7 vs 1.4e-6 '
                                  'of the fp32 fma chain); attention / softmax / LayerNorm / geometry in fp32'},
-            'roofline': {'bound': 'hbm', 'kernel': 'attn_fused_kernel (qcn_attn_fused_f32)', 'achieved': achieved,
+            'roofline': {'bound': 'hbm', 'kernel': 'attn_modes_kernel + attn_fused_kernel (qcn_attn_modes_f32, qcn_attn_fused_f32: every positional attention launch)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'launches': launches, 'avg_launch_us': attn_ms * 1e3 / max(launches, 1),
                          'alg_bytes_per_launch': attn_bytes / max(launches, 1),
-                         'formula': '1552*E + 1024*n_dst (SURVEY 8(d), r-projection fused; E counts the reference\'s mode-replicated edges); k / v gathers are mostly cache-served, so achieved can exceed the HBM peak: '
-                                    'traffic is what reached the memory side', 'traffic': traffic},
+                         'formula': '1552*E + 1024*n_dst (SURVEY 8(d), r-projection fused) with E = the edges a launch processes: a mode-replicated '
+                                    'relation is processed once per base edge for all K modes; traffic = HBM bytes per launch (PMC)', 'traffic': traffic},
             'exact_f32_mfma': None if exact_ms is None else
             {'ms_per_step': exact_ms, 'value': batch_size / (exact_ms * 1e-3), 'unit': 'scenarios/sec',
              'max_rel_diff_loc_refine_pos': float((pred_exact['loc_refine_pos'] - pred['loc_refine_pos']).abs().max()

@@ -4,7 +4,7 @@ import csv, glob, sys, json
 
 
 def load(d, counter):
-    f = glob.glob(d + '/*/*counter_collection.csv')[0]
+    f = (glob.glob(d + '/*/*counter_collection.csv') + glob.glob(d + '/*counter_collection.csv'))[0]
     rows = [r for r in csv.DictReader(open(f)) if r['Counter_Name'] == counter]
     return rows
 
@@ -20,7 +20,11 @@ cal_w = by_kernel(write, 'row_normalize')[-3:]
 # counter unit is KiB per dispatch; calibration = known bytes / reported bytes in this access width (8 B per lane)
 kf = cal_bytes / (sum(cal_f) / len(cal_f) * 1024.0)
 kw = cal_bytes / (sum(cal_w) / len(cal_w) * 1024.0)
-af, aw = by_kernel(fetch, 'attn_fused_kernel'), by_kernel(write, 'attn_fused_kernel')
+def attn(rows):
+    return [float(r['Counter_Value']) for r in rows if 'attn_fused_kernel' in r['Kernel_Name'] or 'attn_modes' in r['Kernel_Name']]
+
+
+af, aw = attn(fetch), attn(write)
 n = len(af) // 2            # two predict calls; take the second (warm) one
 af, aw = af[n:], aw[n:]
 out = {'calibration': {'known_bytes': cal_bytes, 'fetch_factor': kf, 'write_factor': kw,

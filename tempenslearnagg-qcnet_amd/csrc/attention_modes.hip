@@ -699,7 +699,8 @@ extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v
     if (const char *env = getenv("QCN_MODES_WG_PER_CU")) { const int want = atoi(env); if (want >= 1 && want <= 8) per_cu = want; }
     int64_t grid = n_rows < 256 * per_cu ? n_rows : 256 * per_cu;
     hipStream_t s = qcn_stream(stream);
-    void *token = qcn_prof_begin(QCN_PROF_ATTN_FUSED, 1552.0 * (double)num_edges * (double)rep + 1024.0 * (double)n_dst, s);
+    // algorithmic bytes: every base edge is processed once for all rep modes (rhat row + k row + v row + indices)
+    void *token = qcn_prof_begin(QCN_PROF_ATTN_FUSED, 1552.0 * (double)num_edges + 1024.0 * (double)n_dst, s);
     // QCN_MODES_LEAN=1: the two-workgroups-per-CU variant (same results; measured equal on cfg3, kept for A/B runs)
     const char *lean_env = getenv("QCN_MODES_LEAN");
     const bool lean = lean_env && atoi(lean_env) != 0;
