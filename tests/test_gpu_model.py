@@ -142,6 +142,35 @@ def test_temp_ens_learn_agg_vs_oracle():
     assert torch.allclose(got['pi_softmax'].sum(-1), torch.ones(batch['agent']['num_nodes'], device=DEV), atol=1e-5)
 
 
+def test_fast_path_switches_do_not_change_predictions():
+    """The preparation stream (utils/prep.py) only moves launches to a second stream: bit-identical predictions with it
+    off, and across repeated calls (the cross-call overlap of stream work).  The mode-replicated attention kernel
+    (qcn_attn_modes_f32) against the VALU kernel (qcn_attn_fused_f32) on the same model: rounding only."""
+    from tempenslearnagg_qcnet_amd.layers import attention_layer
+    from tempenslearnagg_qcnet_amd.utils import prep
+    cfg = config_scene('tiny')
+    model = _model(cfg, seed=5).to(DEV)
+    batch = make_batch([0, 1, 2], **cfg['scene']).to(DEV)
+    keys = ('traj_refine', 'pi_softmax', 'final_m')
+    with torch.no_grad():
+        first = model.predict(batch)
+        again = [model.predict(batch) for _ in range(3)]
+        torch.cuda.synchronize()
+        try:
+            prep.ENABLED = False
+            inline = model.predict(batch)
+            attention_layer.USE_ATTN_MODES = False
+            fused = model.predict(batch)
+        finally:
+            prep.ENABLED = True
+            attention_layer.USE_ATTN_MODES = True
+    for k in keys:
+        for other in again:
+            assert torch.equal(first[k], other[k]), k
+        assert torch.equal(first[k], inline[k]), k
+        assert rel_err(first[k], fused[k]) < 1e-5, k
+
+
 def test_ragged_batch_with_dead_agents_vs_oracle():
     """Ragged inputs: scenarios of different agent / polygon counts in one batch, one agent that is never valid, one
     that is valid in the history but not predicted, and one scenario with a single polygon — the full ten-frame pass
