@@ -13,7 +13,7 @@ torch.manual_seed(0)
 K, n_rows = 6, 16000
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 which = sys.argv[2].split(',') if len(sys.argv) > 2 else ['pl2m', 't2m', 'a2m']
-shapes = {'pl2m': (124, 48000, True), 't2m': (27, 108800, True), 'a2m': (40, 16000, False)}
+shapes = {'pl2m': (124, 4800, True), 't2m': (27, 108800, True), 'a2m': (40, 16000, False)}     # pl2m: the folded polygon table
 for name in which:
     deg_mean, n_src, has_eid = shapes[name]
     deg = torch.randint(max(deg_mean // 2, 1), deg_mean * 3 // 2 + 1, (n_rows,), device=dev)

@@ -45,25 +45,6 @@ __device__ __forceinline__ float dpp_mov(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
 }
 
-// reductions over the 16 lanes of a DPP row (all 16 lanes get the result)
-__device__ __forceinline__ float row16_max(float v)
-{
-    v = fmaxf(v, dpp_mov<0xB1>(v));    // quad_perm [1,0,3,2]
-    v = fmaxf(v, dpp_mov<0x4E>(v));    // quad_perm [2,3,0,1]
-    v = fmaxf(v, dpp_mov<0x141>(v));   // row_half_mirror
-    v = fmaxf(v, dpp_mov<0x140>(v));   // row_mirror
-    return v;
-}
-
-__device__ __forceinline__ float row16_sum(float v)
-{
-    v += dpp_mov<0xB1>(v);
-    v += dpp_mov<0x4E>(v);
-    v += dpp_mov<0x141>(v);
-    v += dpp_mov<0x140>(v);
-    return v;
-}
-
 __device__ __forceinline__ void wave_lds_fence()
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -110,16 +91,73 @@ __device__ __forceinline__ TileIdx load_tile_idx(const ModesArgs &a, const Tile 
     return x;
 }
 
-__device__ __forceinline__ uint32_t node_of(const ModesArgs &a, int row, int mode)
+// Byte offsets of destination rows: node(row, mode) * 512 = row_term(row) (uniform, scalar unit) + a per-lane constant of
+// the mode, so the per-tile address work is one add.
+struct NodeAddr {
+    uint32_t q_lane;          // q: mode = min(lane & 15, rep - 1), + 64 w + 16 g
+    uint32_t o_lane[4];       // out: mode = 4 g + r, + 64 w + 4 i
+    uint32_t row_mul;         // row_term = row * row_mul
+};
+
+__device__ __forceinline__ NodeAddr make_node_addr(const ModesArgs &a, int wave, int lane)
 {
-    return a.layout == 1 ? (uint32_t)mode * (uint32_t)a.n_rows + (uint32_t)row : (uint32_t)row * (uint32_t)a.rep + (uint32_t)mode;
+    const int i = lane & 15, g = lane >> 4;
+    const uint32_t mode_mul = a.layout == 1 ? (uint32_t)a.n_rows * 512u : 512u;
+    NodeAddr n;
+    n.row_mul = a.layout == 1 ? 512u : (uint32_t)a.rep * 512u;
+    n.q_lane = (uint32_t)min(i, a.rep - 1) * mode_mul + 64u * wave + 16u * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) n.o_lane[r] = (uint32_t)(4 * g + r) * mode_mul + 64u * wave + 4u * i;
+    return n;
 }
 
 // q[node(row, mode = i)][16 w + 4 g .. + 3] (lanes with i >= rep read mode rep - 1 and are zeroed at the use)
-__device__ __forceinline__ f32x4 load_q(const ModesArgs &a, int row, int wave, int lane)
+__device__ __forceinline__ f32x4 load_q(const ModesArgs &a, const NodeAddr &n, int row)
 {
-    const int i = lane & 15, g = lane >> 4;
-    return ld_off<f32x4>(a.q, node_of(a, row, min(i, a.rep - 1)) * 512u + 64u * wave + 16u * g);
+    return ld_off<f32x4>(a.q, (uint32_t)row * n.row_mul + n.q_lane);
+}
+
+// sum over the 16 lanes of every DPP row, four independent values at once (see row16_max4)
+__device__ __forceinline__ void row16_sum4(float (&v)[4])
+{
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %2, %2, %2 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %3, %3, %3 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+}
+
+// Row epilogue: out[node(row, mode = 4 g + r)][16 w + i] = o / (l + 1e-16) + (l / (l + 1e-16)) bias   (PyG softmax
+// denominator; l, o the running sum / weighted sum of the row's softmax)
+__device__ __forceinline__ void store_row_out(const ModesArgs &a, const NodeAddr &n, int row, int g, const float (&l)[4],
+                                              const f32x4 &o, float bias)
+{
+    float ls[4] = {l[0], l[1], l[2], l[3]};
+    row16_sum4(ls);
+    const uint32_t row_term = (uint32_t)row * n.row_mul;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float den = ls[r] + 1e-16f;
+        float inv = __builtin_amdgcn_rcpf(den);
+        inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);    // one Newton step on the hardware reciprocal
+        if (4 * g + r < a.rep)
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (row_term + n.o_lane[r])) = fmaf(o[r], inv, ls[r] * inv * bias);
+    }
 }
 
 // One ring slot: the tile's 16 rhat rows (split f16), 16 k rows and 16 v rows (fp32), 512 B each, as 16-B chunks with
@@ -259,7 +297,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
     const float usc_k = scales[0], usc_v = scales[1];
     const float bias = a.bv[16 * wave + i];
     float *const s_tw = s_t[wave];
-    const uint32_t out_lane = 64u * wave + 4u * i;        // byte offset of this lane's channel inside an output row
+    const NodeAddr na = make_node_addr(a, wave, lane);
 
     // per-lane LDS byte offsets inside a slot (tile independent)
     int r_off[4], v_off[4];
@@ -274,10 +312,8 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
     for (int row = row_begin; row < row_end; ++row) {
         if (rowptr_at(a, row + 1) > rowptr_at(a, row)) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int mode = 4 * g + r;
-            if (mode < a.rep) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, row, mode) * 512u + out_lane)) = 0.f;
-        }
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.rep) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + ((uint32_t)row * na.row_mul + na.o_lane[r])) = 0.f;
     }
 
     Tile tl[kTiles];
@@ -341,7 +377,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
                 const Tile t = safe(tl[J]);
                 const TileIdx x = load_tile_idx<HAS_EID>(a, t, wave, lane);
                 issue_tile_dma(a, x, slot_of(ph), wave, lane);
-                qring[J] = load_q(a, t.row, wave, lane);
+                qring[J] = load_q(a, na, t.row);
                 idx[J] = x;
             }
         };
@@ -379,7 +415,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         STAMP(0)
         issue_tile_dma(a, idx[SB], slot_of(std::integral_constant<int, SB>{}), wave, lane);
         STAMP(1)
-        qring[SB] = load_q(a, tb.row, wave, lane);
+        qring[SB] = load_q(a, na, tb.row);
         idx[SC] = load_tile_idx<HAS_EID>(a, tc, wave, lane);
         STAMP(2)
 
@@ -437,17 +473,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 
         const bool last = tl[1].row != t0.row;                  // last tile of its row
         if (last) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ls = row16_sum(l[r]);
-                const float den = ls + 1e-16f;                  // PyG softmax denominator
-                float inv = __builtin_amdgcn_rcpf(den);
-                inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);    // one Newton step on the hardware reciprocal
-                const int mode = 4 * g + r;
-                if (mode < a.rep)
-                    *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, t0.row, mode) * 512u + out_lane)) =
-                        fmaf(o[r], inv, ls * inv * bias);
-            }
+            store_row_out(a, na, t0.row, g, l, o, bias);
         }
         STAMP(4)
         if (tl[1].row < 0) return true;
@@ -514,7 +540,7 @@ __global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesAr
     const float usc_k = scales[0], usc_v = scales[1];
     const float bias = a.bv[16 * wave + i];
     float *const s_tw = s_t[wave];
-    const uint32_t out_lane = 64u * wave + 4u * i;
+    const NodeAddr na = make_node_addr(a, wave, lane);
     const int r_base = i * kRowBytes, r_x = 16 * i;       // rhat chunk of k-step ks: r_base + ((64 ks + 16 g) ^ r_x)
     const int k_off = i * kRowBytes + 16 * ((4 * wave + g) ^ i);
     const int v_base = 4 * g * kRowBytes + 4 * (i & 3), v_c = 4 * wave + (i >> 2);
@@ -522,10 +548,8 @@ __global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesAr
     for (int row = row_begin; row < row_end; ++row) {
         if (rowptr_at(a, row + 1) > rowptr_at(a, row)) continue;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int mode = 4 * g + r;
-            if (mode < a.rep) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, row, mode) * 512u + out_lane)) = 0.f;
-        }
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.rep) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + ((uint32_t)row * na.row_mul + na.o_lane[r])) = 0.f;
     }
 
     Tile t0 = first_tile(a, row_begin, row_end);
@@ -555,7 +579,7 @@ __global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesAr
 
         const bool first = t0.first;
         if (first) {                    // q is used after the projection MFMAs: its latency hides behind them
-            qa = load_q(a, t0.row, wave, lane) * (0.25f * kLog2e);
+            qa = load_q(a, na, t0.row) * (0.25f * kLog2e);
             if (i >= a.rep) qa = f32x4{0.f, 0.f, 0.f, 0.f};
             o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -608,17 +632,7 @@ __global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesAr
 
         const bool last = t1.row != t0.row;
         if (last) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float ls = row16_sum(l[r]);
-                const float den = ls + 1e-16f;
-                float inv = __builtin_amdgcn_rcpf(den);
-                inv = fmaf(fmaf(-den, inv, 1.0f), inv, inv);
-                const int mode = 4 * g + r;
-                if (mode < a.rep)
-                    *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + (node_of(a, t0.row, mode) * 512u + out_lane)) =
-                        fmaf(o[r], inv, ls * inv * bias);
-            }
+            store_row_out(a, na, t0.row, g, l, o, bias);
         }
         if (t1.row < 0) return true;
         // everything older than this iteration's late loads (indices, q of a first tile, output stores of a last tile)
