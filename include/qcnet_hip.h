@@ -256,6 +256,58 @@ int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const f
  * of attn_prenorm_r, layers/attention_layer.py:63,82). */
 int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);
 
+/* N3 — the state updates of every metric class of the reference in one launch (metrics/brier.py:37-52,
+ * min_ade.py:36-54, min_ahe.py:37-53, min_fde.py:36-45, min_fhe.py:36-48, mr.py:38-54, prob_mr.py:38-59) after
+ * valid_filter (metrics/utils.py:59-82) and the per-sample topk (metrics/utils.py:22-56).
+ *   pred [n, n_modes, n_steps, pred_dim], prob [n, n_modes] or NULL (uniform), target [n, n_steps, target_dim],
+ *   valid [n, n_steps] uint8 or NULL (all valid), select [n] uint8 or NULL (all; the eval mask of
+ *   predictors/temp_ens_learn_agg.py:250-254 without the boolean-index copies).
+ *   pos_dim: leading components compared by the displacement norms.  pred_head: component of pred holding the heading,
+ *   -1 = no heading (the AHE / FHE columns are 0), -2 = the direction of the predicted motion vector with the origin as
+ *   step -1 (temp_ens_learn_agg.py:255-260, fused).  target_head: component of target holding the heading.
+ *   max_guesses as the classes' ctor argument (n_modes <= 8); keep_invalid_final_step as valid_filter's.
+ * record [n, QCN_METRIC_RECORD] fp32: what each class adds to its `sum` for that sample, column per (class, criterion);
+ * QCN_METRIC_COUNTED is 1 for a sample valid_filter keeps and the whole record 0 otherwise; columns 13-15 hold the
+ * FDE-best mode, the ADE-best mode and the last valid step (diagnostics). */
+#define QCN_METRIC_RECORD 16
+enum {
+    QCN_METRIC_BRIER_FDE = 0, QCN_METRIC_BRIER_ADE = 1, QCN_METRIC_ADE_FDE = 2, QCN_METRIC_ADE_ADE = 3,
+    QCN_METRIC_AHE_FDE = 4, QCN_METRIC_AHE_ADE = 5, QCN_METRIC_FDE = 6, QCN_METRIC_FHE = 7, QCN_METRIC_MISS_FDE = 8,
+    QCN_METRIC_MISS_MAXDE = 9, QCN_METRIC_PROBMISS_FDE = 10, QCN_METRIC_PROBMISS_MAXDE = 11, QCN_METRIC_COUNTED = 12
+};
+int qcn_motion_metrics_f32(const float *pred, int pred_dim, const float *prob, const float *target, int target_dim,
+                           const uint8_t *valid, const uint8_t *select, int64_t n, int n_modes, int n_steps, int pos_dim,
+                           int pred_head, int target_head, int max_guesses, int keep_invalid_final_step,
+                           float miss_threshold, float *record, void *stream);
+
+/* N3 — regression targets in the agent frame (predictors/temp_ens_learn_agg.py:104-121 get_ground_truth):
+ * out[a, t - first_step] = [R(-theta_a) (xy[a, t] - xy[a, origin_step]), z[a, t] - z[a, origin_step] (0 for pos_dim 2),
+ * wrap_angle(heading[a, t] - theta_a)], theta_a = heading[a, origin_step], for t in [first_step, first_step + n_steps).
+ * position [n_agents, n_total_steps, pos_dim] (pos_dim 2 or 3), heading [n_agents, n_total_steps], out [n_agents, n_steps, 4]
+ * (16-byte aligned). */
+int qcn_to_agent_frame_f32(const float *position, const float *heading, int64_t n_agents, int n_total_steps, int pos_dim,
+                           int origin_step, int first_step, int n_steps, float *out, void *stream);
+
+/* N3 — predicted trajectories back in the world frame (predictors/qcnet_sliding.py:179-192, visualize.py:17-30 postprocess):
+ * out[i, j] = traj[rows[i], j, :2] [[cos, sin], [-sin, cos]] + xy[rows[i], origin_step] for the per_agent = modes * steps
+ * points j of an agent.  traj [n_agents, per_agent, traj_dim]; rows [n_rows] int64 agent ids (the eval mask's indices) or
+ * NULL (rows = 0..n_rows-1); out [n_rows, per_agent, 2] (8-byte aligned). */
+int qcn_to_world_frame_f32(const float *traj, int traj_dim, const float *position, const float *heading,
+                           const int64_t *rows, int64_t n_rows, int per_agent, int n_total_steps, int pos_dim,
+                           int origin_step, float *out, void *stream);
+
+/* N3 — the NMS ensembling baseline of the sliding-window evaluation (utils/nms.py:11-38 nms, scored as
+ * predictors/qcnet_sliding.py:48-54 calculate_metrics inside the loop :294-317), every (agent, window size) at once.
+ *   traj [n_agents, n_cand_total, n_steps, 2] world-frame candidates (window-major: the reference stacks the frames
+ *   time_shift = 10 .. 1, each with cand_per_window modes), conf [n_agents, n_cand_total], gt [n_agents, n_steps, 2].
+ *   Window w (0-based) selects among the first (w + 1) * cand_per_window candidates; n_cand_total <= 64,
+ *   n_select <= cand_per_window (the reference's top-up loop needs as many candidates as selections).
+ * selected [n_agents, n_windows, n_select] int32: candidate indices in selection order; score [n_agents, n_windows, 3]:
+ * min FDE, min ADE, miss (min FDE > miss_threshold).  Equal confidences are taken higher index first. */
+int qcn_nms_select_f32(const float *traj, const float *conf, const float *gt, int64_t n_agents, int n_cand_total,
+                       int n_steps, int n_windows, int cand_per_window, int n_select, float radius, float miss_threshold,
+                       int *selected, float *score, void *stream);
+
 /* Optional per-launch timing of the hand-written kernels with hipEvents on the launch stream (bench.py roofline
  * leg).  qcn_prof_enable(mask) records the kernel families whose bit (1 << kind) is set
  * (negative: all, 0: off; each recorded launch costs two event records on the stream, so time only what is reported); qcn_prof_collect(kind, ...) synchronises the recorded events of one

@@ -128,5 +128,38 @@ def main() -> None:
     print('wrote %d arrays to %s' % (len(blobs), os.path.join(OUT, 'ref_layers.npz')))
 
 
+def main_nms() -> None:
+    """tests/golden/ref_nms.npz from the reference's own utils/nms.py (pure numpy, imported by file path): clustered
+    synthetic candidate sets of every window size 6 .. 60, with the selections the reference makes."""
+    ref = _load('_ref_nms', os.path.join(REF, 'utils', 'nms.py'))
+    rng = np.random.default_rng(77)
+    n_agents, n_cand, n_steps = 24, 60, 50
+    trajs = np.empty((n_agents, n_cand, n_steps, 2), dtype=np.float32)
+    conf = np.empty((n_agents, n_cand), dtype=np.float32)
+    sel = np.empty((n_agents, 10, 6), dtype=np.int64)
+    sel_conf = np.empty((n_agents, 10, 6), dtype=np.float32)
+    for a in range(n_agents):
+        # end points in a few clusters (tight, so suppression and the top-up branch both happen) plus spread ones
+        n_clusters = 2 + a % 5
+        centres = rng.uniform(-30, 30, size=(n_clusters, 2))
+        which = rng.integers(0, n_clusters, size=n_cand)
+        spread = np.where(rng.random(n_cand) < (0.2 if a % 3 else 0.0), 8.0, 0.8)[:, None]
+        ends = centres[which] + rng.normal(size=(n_cand, 2)) * spread
+        ramp = np.linspace(0.02, 1.0, n_steps)[None, :, None]
+        trajs[a] = (ends[:, None, :] * ramp + rng.normal(size=(n_cand, n_steps, 2)) * 0.05).astype(np.float32)
+        logits = rng.normal(size=(10, 6))
+        conf[a] = (np.exp(logits) / np.exp(logits).sum(axis=1, keepdims=True)).reshape(-1).astype(np.float32)
+        for w in range(1, 11):
+            out = trajs[a, :6 * w].copy()
+            clfs = conf[a, :6 * w].copy()
+            t_sel, c_sel = ref.nms(out, clfs)
+            idx = [int(np.flatnonzero((out == t).all(axis=(1, 2)))[0]) for t in t_sel]
+            sel[a, w - 1], sel_conf[a, w - 1] = idx, c_sel
+    gt = (trajs[:, 0] + rng.normal(size=(n_agents, n_steps, 2)) * 0.7).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, 'ref_nms.npz'), trajs=trajs, conf=conf, gt=gt, selected=sel, selected_conf=sel_conf)
+    print('wrote ref_nms.npz: %d agents, selections %s' % (n_agents, sel.shape))
+
+
 if __name__ == '__main__':
     main()
+    main_nms()

@@ -582,3 +582,117 @@ def attn_modes(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat_split: to
                                              _stream(dev)),
                'qcn_attn_modes_f32')
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# evaluation metrics and frame transforms (N3)
+# ------------------------------------------------------------------------------------------------
+METRIC_RECORD = 16  # QCN_METRIC_RECORD
+METRIC_COLUMNS = {'brier_fde': 0, 'brier_ade': 1, 'ade_fde': 2, 'ade_ade': 3, 'ahe_fde': 4, 'ahe_ade': 5, 'fde': 6, 'fhe': 7,
+                  'miss_fde': 8, 'miss_maxde': 9, 'probmiss_fde': 10, 'probmiss_maxde': 11, 'counted': 12,
+                  'best_fde_mode': 13, 'best_ade_mode': 14, 'last_valid_step': 15}
+HEAD_NONE, HEAD_FROM_MOTION = -1, -2
+
+
+def _as_u8(mask: Optional[torch.Tensor], name: str, device, shape) -> Optional[torch.Tensor]:
+    if mask is None:
+        return None
+    if mask.dtype == torch.bool:
+        mask = mask.contiguous().view(torch.uint8)
+    elif mask.dtype != torch.uint8:
+        mask = (mask != 0).contiguous().view(torch.uint8)
+    mask = mask.contiguous()
+    _require(mask, name, torch.uint8, device, shape)
+    return mask
+
+
+def motion_metrics(pred: torch.Tensor, target: torch.Tensor, prob: Optional[torch.Tensor] = None,
+                   valid_mask: Optional[torch.Tensor] = None, select: Optional[torch.Tensor] = None, pos_dim: Optional[int] = None,
+                   pred_head: int = HEAD_NONE, target_head: int = -1, max_guesses: int = 6,
+                   keep_invalid_final_step: bool = True, miss_threshold: float = 2.0) -> torch.Tensor:
+    """qcn_motion_metrics_f32: per-sample records [n, 16] (columns: METRIC_COLUMNS) of every metric class's state update.
+    pred [n, K, T, Dp], target [n, T, Dt], prob [n, K], valid_mask [n, T], select [n]."""
+    dev = pred.device
+    if pred.dim() != 4 or target.dim() != 3:
+        raise ValueError('pred must be [n, modes, steps, dim] and target [n, steps, dim]')
+    n, k, t, dp = pred.shape
+    dt = target.size(2)
+    pred = pred.contiguous()
+    target = target.contiguous()
+    _require(pred, 'pred', torch.float32, dev, (n, k, t, dp))
+    _require(target, 'target', torch.float32, dev, (n, t, dt))
+    if prob is not None:
+        prob = prob.contiguous()
+        _require(prob, 'prob', torch.float32, dev, (n, k))
+    valid_mask = _as_u8(valid_mask, 'valid_mask', dev, (n, t))
+    select = _as_u8(select, 'select', dev, (n,))
+    if pos_dim is None:
+        pos_dim = dp if pred_head < 0 else dp - 1
+    if target_head < 0:
+        target_head = dt + target_head
+    record = torch.empty(n, METRIC_RECORD, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_motion_metrics_f32(_ptr(pred), dp, _ptr(prob), _ptr(target), dt, _ptr(valid_mask), _ptr(select), n, k,
+                                                 t, int(pos_dim), int(pred_head), int(target_head), int(max_guesses),
+                                                 int(bool(keep_invalid_final_step)), float(miss_threshold), _ptr(record),
+                                                 _stream(dev)), 'qcn_motion_metrics_f32')
+    return record
+
+
+def to_agent_frame(position: torch.Tensor, heading: torch.Tensor, origin_step: int, first_step: int,
+                   n_steps: Optional[int] = None) -> torch.Tensor:
+    """qcn_to_agent_frame_f32: [A, n_steps, 4] targets (x, y, z, heading) in the frame of each agent's pose at
+    ``origin_step`` (predictors/temp_ens_learn_agg.py:104-121)."""
+    dev = position.device
+    a, total, pd = position.shape
+    _require(position, 'position', torch.float32, dev, (a, total, pd))
+    _require(heading, 'heading', torch.float32, dev, (a, total))
+    if n_steps is None:
+        n_steps = total - first_step
+    out = torch.empty(a, n_steps, 4, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_to_agent_frame_f32(_ptr(position), _ptr(heading), a, total, pd, int(origin_step), int(first_step),
+                                                 int(n_steps), _ptr(out), _stream(dev)), 'qcn_to_agent_frame_f32')
+    return out
+
+
+def to_world_frame(traj: torch.Tensor, position: torch.Tensor, heading: torch.Tensor, origin_step: int,
+                   rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """qcn_to_world_frame_f32: [n_rows, K, T, 2] world-frame trajectories of the agents ``rows`` (all agents when None) from
+    agent-frame ``traj`` [A, K, T, D] (predictors/qcnet_sliding.py:179-192)."""
+    dev = traj.device
+    a, k, t, d = traj.shape
+    traj = traj.contiguous()
+    _require(traj, 'traj', torch.float32, dev, (a, k, t, d))
+    _require(position, 'position', torch.float32, dev, (a, None, None))
+    _require(heading, 'heading', torch.float32, dev, (a, position.size(1)))
+    if rows is not None:
+        rows = rows.contiguous()
+        _require(rows, 'rows', torch.int64, dev, (None,))
+        if rows.numel() and (int(rows.min()) < 0 or int(rows.max()) >= a):
+            raise ValueError('rows out of range')
+    n_rows = a if rows is None else rows.numel()
+    out = torch.empty(n_rows, k, t, 2, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_to_world_frame_f32(_ptr(traj), d, _ptr(position), _ptr(heading), _ptr(rows), n_rows, k * t,
+                                                 position.size(1), position.size(2), int(origin_step), _ptr(out), _stream(dev)),
+               'qcn_to_world_frame_f32')
+    return out
+
+
+def nms_select(traj: torch.Tensor, conf: torch.Tensor, gt: torch.Tensor, cand_per_window: int = 6, n_select: int = 6,
+               radius: float = 2.5, miss_threshold: float = 2.0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """qcn_nms_select_f32: traj [n, M, T, 2], conf [n, M], gt [n, T, 2] -> (selected [n, W, n_select] int32,
+    score [n, W, 3] = min FDE / min ADE / miss) for the window sizes 1..W = M // cand_per_window (utils/nms.py:11-38)."""
+    dev = traj.device
+    n, m, t, _ = traj.shape
+    traj, conf, gt = traj.contiguous(), conf.contiguous(), gt.contiguous()
+    _require(traj, 'traj', torch.float32, dev, (n, m, t, 2))
+    _require(conf, 'conf', torch.float32, dev, (n, m))
+    _require(gt, 'gt', torch.float32, dev, (n, t, 2))
+    w = m // int(cand_per_window)
+    if w < 1:
+        raise ValueError('fewer candidates than one window holds')
+    selected = torch.empty(n, w, n_select, dtype=torch.int32, device=dev)
+    score = torch.empty(n, w, 3, dtype=torch.float32, device=dev)
+    _lib.check(_lib.lib().qcn_nms_select_f32(_ptr(traj), _ptr(conf), _ptr(gt), n, m, t, w, int(cand_per_window), int(n_select),
+                                             float(radius), float(miss_threshold), _ptr(selected), _ptr(score), _stream(dev)),
+               'qcn_nms_select_f32')
+    return selected, score

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from ..modules import QCNetDecoder, QCNetEncoder
 
 
@@ -74,10 +75,37 @@ class QCNetSliding(nn.Module):
         """Agent frame → world frame for the focal tracks, sliced to the common horizon
         (predictors/qcnet_sliding.py:179-197)."""
         T = self.num_historical_steps
+        rows = (data['agent']['category'] == 3).nonzero(as_tuple=True)[0]
+        traj = ops.to_world_frame(traj_refine, data['agent']['position'], data['agent']['heading'], T - 1 + time_shift, rows)
+        return traj[:, :, 10 - time_shift: 10 - time_shift + 50], F.softmax(pi[rows], dim=-1)
+
+    @torch.no_grad()
+    def validation_step(self, data, batch_idx: int = 0) -> Dict[str, torch.Tensor]:
+        """The sliding-window NMS baseline of the reference (:276-317): the frames time_shift = 10 .. 1 are predicted,
+        moved to the world frame, and for every window size 1..10 the 6 * w candidates go through NMS and are scored
+        against the future from step 60 on.  The reference does this per agent and window in numpy on the host
+        (utils/nms.py); here every (agent, window) is one wave of ``qcn_nms_select_f32``.
+        Returns ``selected`` [n_eval, 10, 6] (candidate indices), ``score`` [n_eval, 10, 3] (min FDE, min ADE, miss),
+        ``single_score`` (the latest frame alone, :295-296) and ``miss_count_by_nms`` [10] (:316-317)."""
+        trajs, clsfs = [], []
+        for time_shift in range(10, 0, -1):
+            pred, _ = self(data, time_shift)
+            traj_refine = pred['loc_refine_pos'][..., :2]
+            traj, pi = self.postprocess(data, traj_refine, pred['pi'], time_shift)
+            trajs.append(traj)
+            clsfs.append(pi)
+        trajs = torch.stack(trajs, dim=1)                                                     # [n_eval, 10, K, 50, 2]
+        clsfs = torch.stack(clsfs, dim=1)
+        n_eval, n_w, k = trajs.shape[:3]
         eval_mask = data['agent']['category'] == 3
-        origin = data['agent']['position'][eval_mask, T - 1 + time_shift]
-        theta = data['agent']['heading'][eval_mask, T - 1 + time_shift]
-        cos, sin = theta.cos(), theta.sin()
-        rot = torch.stack([torch.stack([cos, sin], dim=-1), torch.stack([-sin, cos], dim=-1)], dim=-2)
-        traj = torch.matmul(traj_refine[eval_mask, :, :, :2], rot.unsqueeze(1)) + origin[:, :2].reshape(-1, 1, 1, 2)
-        return traj[:, :, 10 - time_shift: 10 - time_shift + 50], F.softmax(pi[eval_mask], dim=-1)
+        gt = data['agent']['position'][eval_mask, 60:, :2].contiguous()
+        selected, score = ops.nms_select(trajs.reshape(n_eval, n_w * k, trajs.size(3), 2), clsfs.reshape(n_eval, n_w * k), gt,
+                                         cand_per_window=k, n_select=6)
+        # the first frame alone, unfiltered (:295-296): all its K modes
+        disp = torch.norm(trajs[:, 0] - gt.unsqueeze(1), p=2, dim=-1)
+        single_fde = disp[..., -1].min(dim=-1).values
+        single_miss = single_fde > 2.0
+        miss_count = ((~single_miss).unsqueeze(1) & (score[..., 2] > 0)).sum(dim=0)
+        return {'selected': selected, 'score': score, 'trajs': trajs, 'clsfs': clsfs,
+                'single_score': torch.stack([single_fde, disp.mean(dim=-1).min(dim=-1).values, single_miss.float()], dim=-1),
+                'miss_count_by_nms': miss_count}

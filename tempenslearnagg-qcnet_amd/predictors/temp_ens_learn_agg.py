@@ -12,6 +12,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
+from ..metrics import MotionMetrics
 from ..modules import TemporalAggregate
 from ..utils.prep import inputs_ready, run_prep
 from .qcnet_sliding import QCNetSliding
@@ -48,6 +50,28 @@ class TempEnsLearnAgg(nn.Module):
         # in its first num_layers * time_span steps, of which the decoder reads at most a few
         # (modules/qcnet_agent_encoder.py forward_frames_streaming).
         self.stream_encoder = share_map_encoding
+        # Brier / minADE / minADE_best / minAHE / minFDE / minFHE / MR of the reference (:96-102), fed by one launch
+        self.metrics = MotionMetrics(max_guesses=6)
+
+    def get_ground_truth(self, data, time_shift: int = 10) -> torch.Tensor:
+        """Regression targets in the agent frame of step T - 1 + time_shift (reference :104-121), one kernel."""
+        T = self.num_historical_steps
+        data['agent']['target'] = ops.to_agent_frame(data['agent']['position'].contiguous(), data['agent']['heading'].contiguous(),
+                                                     T - 1 + time_shift, T + time_shift)
+        return data['agent']['target']
+
+    @torch.no_grad()
+    def validation_step(self, data, batch_idx: int = 0) -> Dict[str, torch.Tensor]:
+        """The evaluation half of the reference's validation_step (:188-282, losses excluded): prediction, ground truth,
+        and the update of the seven metric states — eval-mask selection, motion-vector headings and all metric addends in
+        one ``qcn_motion_metrics_f32`` launch.  Returns the predictions with the per-agent metric records."""
+        pred = self.predict(data)
+        reg_mask = data['agent']['predict_mask'][:, self.num_historical_steps + 10:]
+        target = self.get_ground_truth(data, time_shift=10)
+        eval_mask = data['agent']['category'] == 3
+        pred['metric_records'] = self.metrics.update(pred['traj_refine'], pred['pi_softmax'], target, reg_mask, eval_mask,
+                                                     output_dim=self.output_dim, output_head=False)
+        return pred
 
     def forward(self, data, time_shift: int, map_enc=None, agent_cache=None
                 ) -> Tuple[Dict[str, torch.Tensor], Dict[str, torch.Tensor]]:

@@ -162,3 +162,37 @@ def test_oracle_full_forward_runs_and_is_batch_consistent():
     A = cfg['scene']['num_agents']
     assert float((both['loc_refine_pos'][A:] - one['loc_refine_pos']).abs().max()) < 1e-4
     assert float((both['pi'][A:] - one['pi']).abs().max()) < 1e-4
+
+
+def test_oracle_nms_matches_reference_golden():
+    """oracle/metrics_oracle.py::nms against the selections of the reference's own utils/nms.py (tests/golden/ref_nms.npz,
+    oracle/make_golden.py::main_nms): every window size 6 .. 60, suppression and top-up branches."""
+    from oracle import metrics_oracle as mo
+    G = load_golden('ref_nms.npz')
+    topped_up = 0
+    for a in range(G['trajs'].shape[0]):
+        for w in range(1, 11):
+            sel, conf = mo.nms(G['trajs'][a, :6 * w], G['conf'][a, :6 * w])
+            assert np.array_equal(sel, G['selected'][a, w - 1])
+            assert np.array_equal(conf, G['selected_conf'][a, w - 1])
+            topped_up += int((np.diff(conf) > 0).any())
+    assert topped_up > 10
+
+
+def test_oracle_metrics_hand_case():
+    """A two-sample case small enough to check by hand (metrics/min_fde.py:41-44, min_ade.py:44-48, brier.py:44-52, mr.py:46-49)."""
+    from oracle import metrics_oracle as mo
+    target = torch.zeros(2, 4, 2)
+    pred = torch.zeros(2, 2, 4, 2)
+    pred[0, 0, :, 0] = 3.0                       # sample 0: mode 0 is 3 m off everywhere, mode 1 is 1 m off
+    pred[0, 1, :, 0] = 1.0
+    pred[1, 0, :, 1] = 4.0                       # sample 1: both modes miss (4 m and 5 m), last valid step is 1
+    pred[1, 1, :, 1] = 5.0
+    valid = torch.tensor([[1, 1, 1, 1], [1, 1, 0, 0]], dtype=torch.bool)
+    prob = torch.tensor([[0.5, 0.5], [3.0, 1.0]])
+    assert mo.metric_update('minFDE', pred, target, prob, valid) == (torch.tensor(5.0, dtype=torch.float64), 2)
+    assert mo.metric_update('minADE', pred, target, prob, valid)[0] == 5.0
+    assert mo.metric_update('MR', pred, target, prob, valid)[0] == 1
+    assert float(mo.metric_update('Brier', pred, target, prob, valid)[0]) == pytest.approx(0.25 + 0.0625)
+    assert float(mo.metric_update('ProbMR', pred, target, prob, valid)[0]) == pytest.approx(0.5 + 1.0)
+    assert mo.metric_update('minFDE', pred, target, prob, valid, keep_invalid_final_step=False)[1] == 1
