@@ -92,7 +92,7 @@ def main() -> None:
         for _ in range(args.warmup):   # same work as a timed step, so first-use kernel loads stay out of the timing
             pred = model.predict(data)
             sharding.gather_records(sharding.focal_records(ids, data, pred), world)
-            sharding.reduce_metric_sums(sharding.endpoint_metric_sums(data, pred), world)
+            sharding.reduce_metric_sums(sharding.validation_metric_sums(data, pred), world)
         barrier()
         ops.prof_enable(True, kinds=[ops.PROF_ATTN_FUSED])
         t0 = time.perf_counter()
@@ -102,7 +102,7 @@ def main() -> None:
             records.append(sharding.focal_records(ids, data, pred))
         # the path's only exchange: gather the per-scenario prediction records and the metric sums
         gathered = sharding.gather_records(torch.cat(records), world)
-        sums = sharding.reduce_metric_sums(sharding.endpoint_metric_sums(data, pred), world)
+        sums = sharding.reduce_metric_sums(sharding.validation_metric_sums(data, pred), world)
         barrier()
         elapsed = time.perf_counter() - t0
         ops.prof_enable(False)
@@ -165,7 +165,7 @@ def main() -> None:
             {'ms_per_step': exact_ms, 'value': batch_size / (exact_ms * 1e-3), 'unit': 'scenarios/sec',
              'max_rel_diff_loc_refine_pos': float((pred_exact['loc_refine_pos'] - pred['loc_refine_pos']).abs().max()
                                                   / pred['loc_refine_pos'].abs().max())},
-            'gathered_records': int(gathered.size(0)), 'metric_sums': [float(x) for x in sums.tolist()],
+            'gathered_records': int(gathered.size(0)), 'metric_sums': dict(zip(sharding.VALIDATION_METRICS, [[float(a), float(b)] for a, b in sums.view(-1, 2).tolist()])),
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(cfg['hparams'], cfg['scene'], model.state_dict(),

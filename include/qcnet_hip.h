@@ -256,6 +256,31 @@ int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const f
  * of attn_prenorm_r, layers/attention_layer.py:63,82). */
 int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);
 
+/* G3 — edge lists that are outer products of two per-example masks: torch_geometric.utils.dense_to_sparse /
+ * utils/graph.py:88-94 bipartite_dense_to_sparse of  adj[b, i, j] = mask_src[b, i] & mask_dst[b, j]  restricted to the band
+ * delta_lo <= j - i <= delta_hi (pass INT32_MIN / INT32_MAX for no band).  Call sites: the temporal graph
+ * (modules/qcnet_agent_encoder.py:129-132: band [1, time_span]), time -> mode and mode -> mode
+ * (modules/qcnet_decoder.py:160-169,213; modules/temporal_aggregate.py:161-170,214).  Output in the reference's order
+ * (row-major nonzero of the dense adjacency): src[e] = b * n + i, dst[e] = b * m + j.
+ * mask_src [n_batch, n], mask_dst [n_batch, m] uint8.  Two passes like the radius search: count [n_batch * n] per source
+ * node, the caller scans it (qcn_exclusive_scan_i32) and allocates E = offset[n_batch * n], fill writes src / dst [E]. */
+int qcn_mask_pairs_count(const uint8_t *mask_src, const uint8_t *mask_dst, int64_t n_batch, int n, int m, int delta_lo,
+                         int delta_hi, int32_t *count, void *stream);
+int qcn_mask_pairs_fill(const uint8_t *mask_src, const uint8_t *mask_dst, int64_t n_batch, int n, int m, int delta_lo,
+                        int delta_hi, const int64_t *offset, int64_t *src, int64_t *dst, void *stream);
+
+/* G4 — torch_geometric.utils.coalesce(edge_index, edge_attr, reduce='max') as utils/graph.py:45-54 merge_edges calls it
+ * (modules/qcnet_map_encoder.py:146): edges sorted by (src, dst), duplicates merged, the largest uint8 attribute kept.
+ * 0 <= src, dst < num_nodes <= 2^27.  Two passes: qcn_coalesce_count sorts inside `workspace`
+ * (qcn_coalesce_workspace_bytes(E) bytes, must stay untouched until the fill) and writes offset [E + 1] (int64; offset[E] =
+ * number of distinct edges, which the caller reads to allocate); qcn_coalesce_fill writes out_src / out_dst [n_out] and
+ * out_attr [n_out] (attr / out_attr may be NULL). */
+size_t qcn_coalesce_workspace_bytes(int64_t num_edges);
+int qcn_coalesce_count(const int64_t *src, const int64_t *dst, const uint8_t *attr, int64_t num_edges, int64_t num_nodes,
+                       void *workspace, size_t workspace_bytes, int64_t *offset, void *stream);
+int qcn_coalesce_fill(const void *workspace, const int64_t *offset, int64_t num_edges, int64_t num_nodes, int64_t *out_src,
+                      int64_t *out_dst, uint8_t *out_attr, void *stream);
+
 /* N3 — the state updates of every metric class of the reference in one launch (metrics/brier.py:37-52,
  * min_ade.py:36-54, min_ahe.py:37-53, min_fde.py:36-45, min_fhe.py:36-48, mr.py:38-54, prob_mr.py:38-59) after
  * valid_filter (metrics/utils.py:59-82) and the per-sample topk (metrics/utils.py:22-56).

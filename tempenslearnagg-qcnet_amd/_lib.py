@@ -83,6 +83,16 @@ def _declare(lib) -> None:
     lib.qcn_to_agent_frame_f32.argtypes = [P, P, c_int64, c_int, c_int, c_int, c_int, c_int, P, P]
     lib.qcn_to_world_frame_f32.restype = c_int
     lib.qcn_to_world_frame_f32.argtypes = [P, c_int, P, P, P, c_int64, c_int, c_int, c_int, c_int, P, P]
+    lib.qcn_mask_pairs_count.restype = c_int
+    lib.qcn_mask_pairs_count.argtypes = [P, P, c_int64, c_int, c_int, c_int, c_int, P, P]
+    lib.qcn_mask_pairs_fill.restype = c_int
+    lib.qcn_mask_pairs_fill.argtypes = [P, P, c_int64, c_int, c_int, c_int, c_int, P, P, P, P]
+    lib.qcn_coalesce_workspace_bytes.restype = c_size_t
+    lib.qcn_coalesce_workspace_bytes.argtypes = [c_int64]
+    lib.qcn_coalesce_count.restype = c_int
+    lib.qcn_coalesce_count.argtypes = [P, P, P, c_int64, c_int64, P, c_size_t, P, P]
+    lib.qcn_coalesce_fill.restype = c_int
+    lib.qcn_coalesce_fill.argtypes = [P, P, c_int64, c_int64, P, P, P, P]
     lib.qcn_nms_select_f32.restype = c_int
     lib.qcn_nms_select_f32.argtypes = [P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P]
     lib.qcn_prof_enable.restype = c_int
@@ -97,6 +107,7 @@ EXPORTED_SYMBOLS = (
     'qcn_attn_fused_f32', 'qcn_row_normalize_f32', 'qcn_fourier_pack_floats', 'qcn_fourier_embed_f32', 'qcn_ln_linear_f32', 'qcn_attn_post_pack_floats', 'qcn_attn_post_f32', 'qcn_gru_f32', 'qcn_prof_enable', 'qcn_prof_collect', 'qcn_set_matmul_mode', 'qcn_get_matmul_mode', 'qcn_gru_pack_floats', 'qcn_fourier_linear_f32', 'qcn_rel_geometry_f32', 'qcn_mlp_heads_pack_floats', 'qcn_mlp_heads_f32',
     'qcn_split_rows_f16', 'qcn_attn_modes_pack_bytes', 'qcn_attn_modes_f32',
     'qcn_motion_metrics_f32', 'qcn_to_agent_frame_f32', 'qcn_to_world_frame_f32', 'qcn_nms_select_f32',
+    'qcn_mask_pairs_count', 'qcn_mask_pairs_fill', 'qcn_coalesce_workspace_bytes', 'qcn_coalesce_count', 'qcn_coalesce_fill',
 )
 
 

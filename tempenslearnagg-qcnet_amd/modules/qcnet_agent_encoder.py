@@ -14,7 +14,7 @@ import torch.nn as nn
 from .. import ops
 from ..layers import AttentionLayer, FourierEmbedding, NormalizedEdgeFeatures
 from ..utils.geometry import angle_between_2d_vectors
-from ..utils.graph import CSRGraph, dense_to_sparse
+from ..utils.graph import CSRGraph, mask_outer_edges
 from ..utils.weight_init import weight_init
 from ..utils.prep import run_prep
 from ._common import node_ptr, rel_geometry
@@ -74,9 +74,7 @@ class QCNetAgentEncoder(nn.Module):
 
     def _temporal_edges(self, mask: torch.Tensor) -> torch.Tensor:
         """dst later than src by at most time_span steps, both valid (reference :129-132); node id a * n + t."""
-        ei = dense_to_sparse(mask.unsqueeze(2) & mask.unsqueeze(1))[0]
-        ei = ei[:, ei[1] > ei[0]]
-        return ei[:, ei[1] - ei[0] <= self.time_span]
+        return mask_outer_edges(mask, mask, 1, self.time_span)     # one enumeration kernel, no dense [A, n, n] adjacency
 
     def _step_ptrs(self, data, n_steps: int, dev):
         """Example boundaries for the spatial searches: one example per (time step, scenario), time-major node ids

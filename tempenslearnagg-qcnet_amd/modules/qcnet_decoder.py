@@ -15,7 +15,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..layers import attention_layer
 from ..layers import AttentionLayer, FourierEmbedding, MLPLayer, NormalizedEdgeFeatures
-from ..utils.graph import CSRGraph, bipartite_dense_to_sparse, dense_to_sparse
+from ..utils.graph import CSRGraph, mask_outer_edges
 from ..utils.weight_init import weight_init
 from ..utils.prep import run_prep
 from ._common import node_ptr, rel_geometry
@@ -175,12 +175,12 @@ class QCNetDecoder(nn.Module):
 
             pos_t = agent['position'][:, ts:T + ts, :2].reshape(-1, 2)
             head_t = agent['heading'][:, ts:T + ts].reshape(-1)
-            ei_t2m_1 = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst[:, -1:].unsqueeze(1))
+            ei_t2m_1 = mask_outer_edges(mask_src, mask_dst[:, -1:])
             r_t2m = rel_geometry(pos_t, pos_m, head_t, head_m, ei_t2m_1, extra=(ei_t2m_1[0] % T) - T + 1)
             # One positional embedding / edge list per (step, agent) pair; the K mode queries of the agent share it
             # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
             r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=r_fmt))
-            ei_t2m = bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))
+            ei_t2m = mask_outer_edges(mask_src, mask_dst)
             g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
             col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
             col = col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt)
@@ -209,7 +209,7 @@ class QCNetDecoder(nn.Module):
             ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
             g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_a2m)
 
-            ei_m2m = dense_to_sparse(mask_dst.unsqueeze(2) & mask_dst.unsqueeze(1))[0]
+            ei_m2m = mask_outer_edges(mask_dst, mask_dst)
             g_m2m = CSRGraph.from_edge_index(ei_m2m, A * K, A * K, validate=False)
             for r in (r_t2m, r_pl2m, r_a2m):
                 r.prepare_for(K)

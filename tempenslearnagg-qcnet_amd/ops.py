@@ -696,3 +696,70 @@ def nms_select(traj: torch.Tensor, conf: torch.Tensor, gt: torch.Tensor, cand_pe
                                              float(radius), float(miss_threshold), _ptr(selected), _ptr(score), _stream(dev)),
                'qcn_nms_select_f32')
     return selected, score
+
+
+# ------------------------------------------------------------------------------------------------
+# mask enumerations and edge merge (G3 / G4)
+# ------------------------------------------------------------------------------------------------
+_NO_BAND = (-(1 << 31), (1 << 31) - 1)
+
+
+def mask_pairs(mask_src: torch.Tensor, mask_dst: torch.Tensor, delta_lo: Optional[int] = None,
+               delta_hi: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """qcn_mask_pairs_count / _fill: the edges (b * n + i, b * m + j) with mask_src[b, i] & mask_dst[b, j] (and
+    delta_lo <= j - i <= delta_hi when a band is given) in row-major order — dense_to_sparse of the outer-product adjacency
+    without materialising it.  Returns ``(edge_index [2, E] int64, offset [B * n + 1] int64)``; one host synchronisation."""
+    dev = mask_src.device
+    if mask_src.dim() != 2 or mask_dst.dim() != 2 or mask_src.size(0) != mask_dst.size(0):
+        raise ValueError('masks must be [B, n] and [B, m]')
+    b, n = mask_src.shape
+    m = mask_dst.size(1)
+    ms = _as_u8(mask_src, 'mask_src', dev, (b, n))
+    md = _as_u8(mask_dst, 'mask_dst', dev, (b, m))
+    lo = _NO_BAND[0] if delta_lo is None else int(delta_lo)
+    hi = _NO_BAND[1] if delta_hi is None else int(delta_hi)
+    lib = _lib.lib()
+    st = _stream(dev)
+    rows = b * n
+    count = torch.zeros(rows + 1, dtype=torch.int32, device=dev)
+    offset = torch.empty(rows + 1, dtype=torch.int64, device=dev)
+    _lib.check(lib.qcn_mask_pairs_count(_ptr(ms), _ptr(md), b, n, m, lo, hi, _ptr(count), st), 'qcn_mask_pairs_count')
+    ws_bytes = lib.qcn_scan_workspace_bytes(rows)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.qcn_exclusive_scan_i32(_ptr(count), rows, _ptr(offset), _ptr(ws), ws_bytes, st), 'qcn_exclusive_scan_i32')
+    num_edges = int(offset[-1].item())
+    edge_index = torch.empty(2, num_edges, dtype=torch.int64, device=dev)
+    if num_edges > 0:
+        _lib.check(lib.qcn_mask_pairs_fill(_ptr(ms), _ptr(md), b, n, m, lo, hi, _ptr(offset), _ptr(edge_index[0]),
+                                           _ptr(edge_index[1]), st), 'qcn_mask_pairs_fill')
+    return edge_index, offset
+
+
+def coalesce_max(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], num_nodes: int
+                 ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
+    """qcn_coalesce_count / _fill: edges sorted by (src, dst), duplicates merged with the largest uint8 attribute."""
+    dev = edge_index.device
+    if edge_index.dim() != 2 or edge_index.size(0) != 2:
+        raise ValueError('edge_index must be [2, E]')
+    e = edge_index.size(1)
+    edge_index = edge_index.contiguous()
+    _require(edge_index, 'edge_index', torch.int64, dev, (2, e))
+    if edge_attr is not None:
+        edge_attr = edge_attr.contiguous()
+        _require(edge_attr, 'edge_attr', torch.uint8, dev, (e,))
+    if e and (int(edge_index.min()) < 0 or int(edge_index.max()) >= int(num_nodes)):
+        raise IndexError('edge_index out of range for num_nodes %d' % num_nodes)
+    lib = _lib.lib()
+    st = _stream(dev)
+    ws_bytes = lib.qcn_coalesce_workspace_bytes(e)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    offset = torch.empty(e + 1, dtype=torch.int64, device=dev)
+    _lib.check(lib.qcn_coalesce_count(_ptr(edge_index[0]), _ptr(edge_index[1]), _ptr(edge_attr), e, int(num_nodes), _ptr(ws), ws_bytes,
+                                      _ptr(offset), st), 'qcn_coalesce_count')
+    n_out = int(offset[-1].item())
+    out_index = torch.empty(2, n_out, dtype=torch.int64, device=dev)
+    out_attr = torch.empty(n_out, dtype=torch.uint8, device=dev) if edge_attr is not None else None
+    if e:
+        _lib.check(lib.qcn_coalesce_fill(_ptr(ws), _ptr(offset), e, int(num_nodes), _ptr(out_index[0]), _ptr(out_index[1]),
+                                         _ptr(out_attr), st), 'qcn_coalesce_fill')
+    return out_index, out_attr

@@ -55,6 +55,26 @@ def endpoint_metric_sums(data, pred: Dict[str, torch.Tensor], time_shift: int = 
     return torch.stack([ade.sum(), n, fde.sum(), n, (fde > 2.0).float().sum(), n])
 
 
+VALIDATION_METRICS = ('Brier', 'minADE', 'minADE_best', 'minAHE', 'minFDE', 'minFHE', 'MR')
+_VALIDATION_COLUMNS = ('brier_fde', 'ade_fde', 'ade_ade', 'ahe_fde', 'fde', 'fhe', 'miss_fde')
+
+
+def validation_metric_sums(data, pred: Dict[str, torch.Tensor], num_historical_steps: int = 50, time_shift: int = 10,
+                           output_dim: int = 2) -> torch.Tensor:
+    """(sum, count) pairs of the reference's seven validation metrics (VALIDATION_METRICS order,
+    predictors/temp_ens_learn_agg.py:264-275) for one batch: ground truth and all metric addends from the HIP kernels
+    (qcn_to_agent_frame_f32 + qcn_motion_metrics_f32), no host round trip.  GPU only."""
+    from . import ops
+    T = num_historical_steps
+    agent = data['agent']
+    target = ops.to_agent_frame(agent['position'].contiguous(), agent['heading'].contiguous(), T - 1 + time_shift, T + time_shift)
+    rec = ops.motion_metrics(pred['traj_refine'], target, prob=pred['pi_softmax'], valid_mask=agent['predict_mask'][:, T + time_shift:],
+                             select=agent['category'] == 3, pos_dim=output_dim, pred_head=ops.HEAD_FROM_MOTION, target_head=-1)
+    tot = rec.sum(dim=0)
+    sums = tot[[ops.METRIC_COLUMNS[c] for c in _VALIDATION_COLUMNS]]
+    return torch.stack([sums, tot[ops.METRIC_COLUMNS['counted']].expand_as(sums)], dim=1).reshape(-1)
+
+
 def gather_records(records: torch.Tensor, world_size: int) -> torch.Tensor:
     """all_gather of per-scenario records from every rank (ragged counts padded to the max), sorted by id."""
     if world_size == 1 or not dist.is_initialized():
@@ -80,14 +100,20 @@ def reduce_metric_sums(sums: torch.Tensor, world_size: int) -> torch.Tensor:
 
 
 def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], object], num_scenarios: int,
-                batch_size: int, rank: int, world_size: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Runs this rank's shard and returns (all records sorted by scenario id, reduced metric sums)."""
+                batch_size: int, rank: int, world_size: int, device,
+                metric_fn: Callable = endpoint_metric_sums) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Runs this rank's shard and returns (all records sorted by scenario id, reduced metric sums).  ``metric_fn(data, pred)``
+    returns the batch's (sum, count) pairs: ``validation_metric_sums`` on the GPU (the reference's seven metrics from the
+    HIP kernel); the default is device-agnostic torch arithmetic so the collectives can be exercised over gloo."""
     records = []
-    sums = torch.zeros(6, device=device)
+    sums = None
     for ids in batches(shard_scenario_ids(num_scenarios, rank, world_size), batch_size):
         data = make_batch_fn(ids).to(device)
         pred = predict_fn(data)
         records.append(focal_records(ids, data, pred))
-        sums += endpoint_metric_sums(data, pred).to(sums.dtype)
+        part = metric_fn(data, pred).float()
+        sums = part if sums is None else sums + part
+    if sums is None:
+        sums = torch.zeros(6, device=device)
     records = torch.cat(records) if records else torch.empty(0, RECORD_WIDTH, device=device)
     return gather_records(records, world_size), reduce_metric_sums(sums, world_size)

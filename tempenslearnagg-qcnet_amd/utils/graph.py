@@ -211,6 +211,15 @@ def dense_to_sparse(adj: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     return torch.stack([b * adj.size(1) + i, b * adj.size(2) + j], dim=0), adj[b, i, j]
 
 
+def mask_outer_edges(mask_src: torch.Tensor, mask_dst: torch.Tensor, delta_lo: Optional[int] = None,
+                     delta_hi: Optional[int] = None) -> torch.Tensor:
+    """``bipartite_dense_to_sparse(mask_src.unsqueeze(2) & mask_dst.unsqueeze(1))`` (= ``dense_to_sparse`` for square
+    masks), optionally restricted to ``delta_lo <= j - i <= delta_hi``, from the HIP enumeration kernel: the dense
+    [B, n, m] adjacency of the reference (modules/qcnet_agent_encoder.py:129-132, modules/qcnet_decoder.py:160-169,213)
+    is never built.  Same edge order as the reference."""
+    return ops.mask_pairs(mask_src, mask_dst, delta_lo, delta_hi)[0]
+
+
 def bipartite_dense_to_sparse(adj: torch.Tensor) -> torch.Tensor:
     """utils/graph.py:88-94 — [B, n, m] mask → src = b*n + i, dst = b*m + j."""
     idx = adj.nonzero(as_tuple=True)
@@ -237,6 +246,11 @@ def coalesce(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor] = None,
     if edge_index.size(1) == 0:
         return (edge_index, edge_attr) if edge_attr is not None else edge_index
     n = int(edge_index.max()) + 1 if num_nodes is None else int(num_nodes)
+    if edge_index.is_cuda and edge_index.dtype == torch.int64 and n <= (1 << 27) and (
+            edge_attr is None or (reduce == 'max' and edge_attr.dtype == torch.uint8 and edge_attr.dim() == 1)):
+        # the reference's case (utils/graph.py:54: reduce='max' over uint8 edge types): HIP sort + merge
+        out_index, out_attr = ops.coalesce_max(edge_index, edge_attr, n)
+        return out_index if edge_attr is None else (out_index, out_attr)
     key = edge_index[0] * n + edge_index[1]
     uniq, inverse = torch.unique(key, sorted=True, return_inverse=True)
     out_index = torch.stack([torch.div(uniq, n, rounding_mode='floor'), uniq % n], dim=0)

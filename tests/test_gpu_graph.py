@@ -161,3 +161,62 @@ def test_rel_geometry_kernel_matches_reference_helpers():
         assert (got == want).float().mean() > 0.99
     empty = ops.rel_geometry(pos_s, pos_d, head_s, head_d, ei[:, :0])
     assert empty.shape == (0, 3)
+
+
+@pytest.mark.parametrize('b,n,m,band,p_src,p_dst', [
+    (7, 59, 59, (1, 10), 0.8, 0.8),          # temporal graph (modules/qcnet_agent_encoder.py:129-132)
+    (50, 50, 6, None, 0.6, 0.9),             # time -> mode (bipartite, modules/qcnet_decoder.py:160-169)
+    (33, 6, 6, None, 0.7, 0.7),              # mode -> mode, self loops kept (:213)
+    (4, 300, 300, (1, 300), 0.5, 0.5),       # time_span >= n: every later step
+    (3, 5, 9, (-2, 3), 1.0, 1.0),            # a band reaching both sides, bipartite
+    (2, 8, 8, None, 0.0, 1.0),               # nothing valid
+])
+def test_mask_pairs_bit_exact_vs_oracle_dense_to_sparse(b, n, m, band, p_src, p_dst):
+    g = torch.Generator().manual_seed(b * 1000 + n)
+    ms = torch.rand(b, n, generator=g) < p_src
+    md = ms.clone() if (n == m and p_src == p_dst) else (torch.rand(b, m, generator=g) < p_dst)
+    adj = ms.unsqueeze(2) & md.unsqueeze(1)
+    want = oracle.dense_to_sparse(adj) if n == m else oracle.bipartite_dense_to_sparse(adj)
+    if n == m:
+        assert torch.equal(want, oracle.bipartite_dense_to_sparse(adj))
+    if band is not None:      # the reference's two filter passes (modules/qcnet_agent_encoder.py:131-132), generalised
+        i, j = want[0] % n, want[1] % m
+        want = want[:, (j - i >= band[0]) & (j - i <= band[1])]
+    lo, hi = band if band is not None else (None, None)
+    got, offset = ops.mask_pairs(ms.to(DEV), md.to(DEV), lo, hi)
+    assert got.dtype == torch.int64 and torch.equal(got.cpu(), want)
+    assert int(offset[-1]) == want.size(1) and offset.numel() == b * n + 1
+    assert torch.equal(G.mask_outer_edges(ms.to(DEV), md.to(DEV), lo, hi).cpu(), want)
+
+
+def test_mask_pairs_empty_and_bad_inputs():
+    e, _ = ops.mask_pairs(torch.zeros(0, 5, dtype=torch.bool, device=DEV), torch.zeros(0, 3, dtype=torch.bool, device=DEV))
+    assert e.shape == (2, 0)
+    with pytest.raises(ValueError):
+        ops.mask_pairs(torch.zeros(2, 5, dtype=torch.bool, device=DEV), torch.zeros(3, 5, dtype=torch.bool, device=DEV))
+    with pytest.raises(pkg._lib.QcnError):
+        ops.mask_pairs(torch.ones(2, 5, dtype=torch.bool, device=DEV), torch.ones(2, 5, dtype=torch.bool, device=DEV), 3, 1)
+
+
+@pytest.mark.parametrize('n_nodes,E,with_attr', [(30, 400, True), (4800, 200000, True), (150, 5000, False), (1, 10, True),
+                                               (1 << 20, 3000, True)])
+def test_coalesce_max_kernel_bit_exact_vs_oracle(n_nodes, E, with_attr):
+    g = torch.Generator().manual_seed(E)
+    ei = torch.randint(0, n_nodes, (2, E), generator=g)
+    ei[:, E // 2:] = ei[:, :E - E // 2]                       # every edge of the first half again (different types)
+    attr = torch.randint(0, 5, (E,), generator=g).to(torch.uint8)
+    wi, wa = oracle.coalesce_max(ei, attr)
+    gi, ga = ops.coalesce_max(ei.to(DEV), attr.to(DEV) if with_attr else None, n_nodes)
+    assert torch.equal(gi.cpu(), wi)
+    if with_attr:
+        assert ga.dtype == torch.uint8 and torch.equal(ga.cpu(), wa)
+    else:
+        assert ga is None
+    # the public utility takes the same route and keeps PyG's return conventions
+    assert torch.equal(G.coalesce(ei.to(DEV), num_nodes=n_nodes).cpu(), wi)
+    ci, ca = G.coalesce(ei.to(DEV), attr.to(DEV), reduce='max')
+    assert torch.equal(ci.cpu(), wi) and torch.equal(ca.cpu(), wa)
+    with pytest.raises(IndexError):
+        ops.coalesce_max(ei.to(DEV) + n_nodes, None, n_nodes)
+    empty, _ = ops.coalesce_max(torch.empty(2, 0, dtype=torch.long, device=DEV), None, 5)
+    assert empty.shape == (2, 0)
