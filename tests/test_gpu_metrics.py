@@ -213,3 +213,15 @@ def test_sliding_nms_baseline_vs_oracle():
             fde, ade, miss = mo.calculate_metrics(cand[sel], gt[a])
             got = out['score'][a, w - 1].cpu().numpy()
             assert abs(got[0] - fde) < 1e-4 * max(1, fde) and abs(got[1] - ade) < 1e-4 * max(1, ade) and int(got[2]) == miss
+
+
+def test_target_builder_on_gpu_equals_host_transform():
+    from tempenslearnagg_qcnet_amd.transforms import TargetBuilder
+    cfg = config_scene('tiny')
+    host = make_batch([0, 1], **cfg['scene'])
+    dev = make_batch([0, 1], **cfg['scene']).to(DEV)
+    tb = TargetBuilder(50, 60)
+    want = tb(host)['agent']['target']
+    got = tb(dev)['agent']['target']
+    assert got.is_cuda and got.shape == want.shape
+    assert rel_err(got[..., :3], want[..., :3]) < TOL and float((got[..., 3].cpu() - want[..., 3]).abs().max()) < 1e-5
