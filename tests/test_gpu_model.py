@@ -259,3 +259,32 @@ def test_scenarios_are_independent_full_size():
     A = SCENE_AV2['num_agents']
     for k in OUT_KEYS:
         assert rel_err(full[k][5 * A:7 * A], part[k]) < 1e-5, k
+
+
+def test_dense_scene_with_neighbour_cap_vs_oracle():
+    """BASELINE.json configs[3] in small: a scene dense enough that radius_graph's neighbour cap (300 + the self hit,
+    modules/qcnet_map_encoder.py:141) truncates EVERY polygon's neighbourhood and the large pl2a / a2a radii of the dense
+    preset connect almost everything — edge lists bit-exact, predictions within tolerance, and the batched ten-frame path
+    agrees with the frame loop on the same scene."""
+    from tempenslearnagg_qcnet_amd.synthetic import HPARAMS_DENSE
+    scene = dict(num_agents=24, num_polygons=360, points_per_polygon=3, map_extent=60.0, agent_extent=40.0)
+    model = _model(dict(hparams=HPARAMS_DENSE))
+    sd = cpu_state_dict(model)
+    batch = make_batch([0, 1], **scene)
+    with torch.no_grad():
+        want_pred, want_enc = oracle.qcnet_forward(sd, batch, 7, HPARAMS_DENSE, p='base_model.')
+        model = model.to(DEV)
+        got_pred, got_enc = model(batch.to(DEV), 7)
+    # every polygon sees all 359 others inside the radius, the cap keeps 300 or 301 of them; dataset edges merge on top
+    per_target = torch.bincount(want_enc['edge_index_pl2pl'][1], minlength=720)
+    assert int(per_target.min()) >= 300 and int(per_target.max()) <= 303
+    _check_edges(got_enc, want_enc, EDGE_KEYS_ENC)
+    _check_edges(got_pred, want_pred, EDGE_KEYS_DEC)
+    for k in OUT_KEYS + ('m',):
+        assert rel_err(got_pred[k], want_pred[k]) < TOL, k
+    with torch.no_grad():
+        fast = model.predict(batch.to(DEV))
+        model.batch_frames = False
+        loop = model.predict(batch.to(DEV))
+    for k in ('traj_refine', 'pi_softmax'):
+        assert rel_err(fast[k], loop[k]) < 1e-5, k
