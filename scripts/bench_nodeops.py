@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from _bootstrap import ensure_package
 ensure_package()
-from tempenslearnagg_qcnet_amd import ops
+from tempenslearnagg_qcnet_amd import ops, _lib
+if os.environ.get('QCN_LIB'):      # a timing variant built by scripts/dbg/build_variant.sh (results are wrong, times only)
+    _lib.LIB_PATH = os.path.abspath(os.environ['QCN_LIB'])
 from tempenslearnagg_qcnet_amd.layers import AttentionLayer, FourierEmbedding
 
 dev = torch.device('cuda:0')

@@ -54,6 +54,44 @@ __device__ __forceinline__ void sync_for_stage()
     __syncthreads();
 }
 
+// Phase skew.  One barrier per matrix keeps the eight waves of a block in lockstep: all of them run a GEMM (two waves per
+// SIMD queue on one MFMA pipe while the vector ALU idles), then all of them run the per-row epilogue (LayerNorm, operand
+// split, sincos: the MFMA pipe idles).  With the skew the block runs as two groups half a phase apart — every wave
+// takes a barrier before AND after each GEMM, group B takes one extra barrier at the start and group A one at the end —
+// so that at any time one wave of a SIMD is in its GEMM while the other one is in its epilogue:
+//   slot      0    1    2    3    4         A: V0 | G0 | V1 | G1 | ...
+//   group A   V0   G0   V1   G1   V2        B:  - | V0 | G0 | V1 | G1 ...
+// Buffer hazards hold at slot granularity: matrix i is read in slots 2i+1 (A) and 2i+2 (B); the pieces of matrix i+1
+// are issued inside those two GEMMs into the other buffer (last read in slot 2i by B) and have landed (vmcnt(0) before
+// every barrier) when A starts G(i+1) in slot 2i+3.  Only blocks of eight waves are skewed (waves w and w + 4 share a SIMD).
+// skew: 0 off, 1 group B = waves 4..7, 2 group B = odd waves (QCN_CHAIN_SKEW, for A/B runs).
+// Measured (same box, 800 k rows): 3-4 % SLOWER for Fourier / attn_post in mode 1, up to 15 % slower in mode 2 — the lockstep
+// is not what holds these kernels back (neither are the LDS weight reads: a build without them gains 6 %), so the default
+// is off; the knob stays for A/B runs.
+struct Skew {
+    bool on, grp_b;
+};
+
+template <int WAVES>
+__device__ __forceinline__ Skew make_skew(int mode, int wave)
+{
+    Skew s;
+    s.on = WAVES == 8 && mode != 0;
+    s.grp_b = mode == 2 ? (wave & 1) != 0 : wave >= 4;
+    return s;
+}
+
+// the skew's extra barriers (every wave of a block takes the same number: 2 per GEMM + 1)
+__device__ __forceinline__ void skew_begin(const Skew &s) { if (s.on && s.grp_b) sync_for_stage(); }
+__device__ __forceinline__ void skew_after_gemm(const Skew &s) { if (s.on) sync_for_stage(); }
+__device__ __forceinline__ void skew_end(const Skew &s) { if (s.on && !s.grp_b) sync_for_stage(); }
+
+__host__ inline int chain_skew_mode(int dflt)
+{
+    if (const char *env = getenv("QCN_CHAIN_SKEW")) { const int m = atoi(env); if (m >= 0 && m <= 2) return m; }
+    return dflt;
+}
+
 // Start the LDS-DMA copy of one packed matrix into LDS buffer `dst`; every wave of the block copies WAVES-th of it.
 template <int WAVES>
 __device__ __forceinline__ void stage_matrix(const float *__restrict__ packed, f32x4 *dst, int wave, int lane)
@@ -169,14 +207,28 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<true> &in, 
     for (int g = 0; g < 32; ++g) {            // g = 4 j + t
         const int j = g >> 2, t = g & 3;
         const half8 ah = __builtin_bit_cast(half8, nh), al = __builtin_bit_cast(half8, nl);
+#ifndef QCN_EXP_NO_MFMA
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], acc[t], 0, 0, 0);
+#else
+        acc[t][g & 15] += (float)ah[0] * (float)in.hi[j][0] + (float)al[1] * (float)in.lo[j][1];
+#endif
+#ifndef QCN_EXP_NO_LDS
         if (g + 1 < 32) { nh = w[(2 * (g + 1)) * 64 + lane]; nl = w[(2 * (g + 1) + 1) * 64 + lane]; }
+#else
+        if (g + 1 < 32) { nh[g & 3] += 1.0f; nl[g & 3] += 1.0f; }
+#endif
+#ifndef QCN_EXP_NO_MFMA
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.lo[j], acc[t], 0, 0, 0);
+#endif
+#ifndef QCN_EXP_NO_STAGE
         if (g % kEvery == 0 && next != nullptr) {
 #pragma unroll
             for (int i = 0; i < kPerSlot; ++i) stage_piece<WAVES>(next, next_dst, wave, lane, (g / kEvery) * kPerSlot + i);
         }
+#endif
+#ifndef QCN_EXP_NO_MFMA
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in.hi[j], acc[t], 0, 0, 0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll

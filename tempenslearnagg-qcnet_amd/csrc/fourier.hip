@@ -29,10 +29,10 @@ constexpr int kVOutG = 0, kVOutBe = kC, kVOutB = 2 * kC, kOutVecs = 3 * kC, kSca
 // sin and cos of an fp32 angle in radians: three-term Cody-Waite reduction by 2 pi (fma, so every step is exact up to the
 // final rounding of the remainder) and the revolution-based hardware v_sin_f32 / v_cos_f32.  Max abs error against the
 // exact sin / cos of the same fp32 angle: 3.7e-7 for |angle| < 6000 (ocml sincosf: 7e-8; scripts/dbg/sincos_acc.hip) at a
-// quarter of its instruction count; angles beyond 2^15 rad take the ocml path.
+// quarter of its instruction count.
+// Valid for |ang| <= 2^15 (the caller takes the ocml path for a lane's whole input dim otherwise, see fourier_kernel).
 __device__ __forceinline__ void sincos_2pi(float ang, float *sn, float *cs)
 {
-    if (__builtin_expect(fabsf(ang) > 32768.0f, 0)) { sincosf(ang, sn, cs); return; }
     const float inv2pi = 0.15915494309189535f;
     const float k = rintf(ang * inv2pi);
     float f = fmaf(-k, 6.28125f, ang);                       // 2 pi = 6.28125 + 1.9350051879882812e-3 + 3.0199159795e-7
@@ -55,7 +55,7 @@ template <int IN, bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__restrict__ x,
                                                              const float *__restrict__ extra, int extra_div,
                                                              const float *__restrict__ pack, float *__restrict__ y,
-                                                             int64_t n_rows, int normalize_out, FourierTail tail)
+                                                             int64_t n_rows, int normalize_out, FourierTail tail, int skew_mode)
 {
     __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
@@ -71,7 +71,9 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     const float *msc = out_vec + kOutVecs;
     Operand<SPLIT> op;
 
+    const Skew skew = make_skew<WAVES>(skew_mode, wave);
     stage_matrix<WAVES>(mats, buf0, wave, lane);
+    skew_begin(skew);
 
     f32x16 acc_y[4];
     fill_zero(acc_y);
@@ -81,10 +83,16 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         const float *dv = vecs + d * kDimVecs;
         const float xv = x[rowc * IN + d];
         // ---- Fourier features of this lane's 32 frequencies: cos in k-steps 0..31, sin in 32..63
+        // One range test per lane and input dim instead of one per angle: |x| max|f| <= 5215 bounds every |angle| of the
+        // lane below 2^15 (three roundings included), where the fast reduction is valid.  Lanes beyond it (positions of
+        // 1e5 m and more, or a huge learned frequency) redo their 32 angles with ocml's sincosf in a cold block of its own:
+        // inlined per angle that code was two thirds of this loop's instructions.
         f32x16 ft[4];
+        float fmx = 0.f;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const f32x4 f4 = *reinterpret_cast<const f32x4 *>(dv + kVFreq + 32 * h + 4 * q);
+            fmx = fmaxf(fmaxf(fmx, fmaxf(fabsf(f4[0]), fabsf(f4[1]))), fmaxf(fabsf(f4[2]), fabsf(f4[3])));
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int s = 4 * q + j;
@@ -94,6 +102,21 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
                 sincos_2pi(ang, &sn, &cs);
                 ft[s >> 4][s & 15] = cs;
                 ft[2 + (s >> 4)][s & 15] = sn;
+            }
+        }
+        if (__builtin_expect(!(fabsf(xv) * fmx <= 5215.0f), 0)) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const f32x4 f4 = *reinterpret_cast<const f32x4 *>(dv + kVFreq + 32 * h + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int s = 4 * q + j;
+                    const float ang = __fmul_rn(__fmul_rn(__fmul_rn(xv, f4[j]), 2.0f), 3.14159265358979323846f);
+                    float sn, cs;
+                    sincosf(ang, &sn, &cs);
+                    ft[s >> 4][s & 15] = cs;
+                    ft[2 + (s >> 4)][s & 15] = sn;
+                }
             }
         }
         // ---- h = W1 [features, x] + b1 : the 129th input column is a rank-1 term folded into the accumulator init
@@ -110,6 +133,7 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         make_operand(op, ft);
         sync_for_stage();
         gemm<WAVES>(acc_h, op, buf0, msc + 4 * d, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
+        skew_after_gemm(skew);
         layer_norm<true, true>(acc_h, dv + kVG1, dv + kVBe1, h, eps);
         // ---- y += W2 h + b2
 #pragma unroll
@@ -123,6 +147,7 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         make_operand(op, acc_h);
         sync_for_stage();
         gemm<WAVES>(acc_y, op, buf1, msc + 4 * d + 2, lane, mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
+        skew_after_gemm(skew);
     }
 
     if (extra != nullptr) {   // summed categorical embeddings (:65-66)
@@ -139,12 +164,14 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     make_operand(op, acc_y);
     sync_for_stage();
     gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
+    skew_after_gemm(skew);
     if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
     if (tail.n_out == 0) {
         if (valid) {
             if (normalize_out == 2) store_row_split(acc_o, reinterpret_cast<_Float16 *>(y), row, h, 2048.0f);
             else store_row(acc_o, y, row, h);
         }
+        skew_end(skew);
         return;
     }
     // ---- tail: the embedding is the operand of n_out more layers (matrix j sits in buffer (j + 1) & 1)
@@ -158,8 +185,10 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         sync_for_stage();
         gemm<WAVES>(acc, op, wlds + ((j + 1) & 1) * kMatVec4, tsc + 2 * j, lane,
                     j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr, wlds + (j & 1) * kMatVec4, wave);
+        skew_after_gemm(skew);
         if (valid) store_row(acc, tail.y[j], row, h);
     }
+    skew_end(skew);
 }
 
 }  // namespace
@@ -180,11 +209,12 @@ static int launch_fourier(const float *x, int input_dim, const float *extra, int
     const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
     const int waves = pick_waves(n_rows, split);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    const int skew_mode = chain_skew_mode(0);
     const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC * (1 + tail.n_out));
     void *token = qcn_prof_begin(QCN_PROF_FOURIER, flops, s);
 #define QCN_LAUNCH(S, W)                                                                                           \
     hipLaunchKernelGGL((fourier_kernel<QCN_IN, S, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, \
-                       n_rows, normalize_out, tail)
+                       n_rows, normalize_out, tail, skew_mode)
     switch (input_dim) {
 #define QCN_IN 0
     case 0: QCN_CHAIN_DISPATCH(split, waves); break;

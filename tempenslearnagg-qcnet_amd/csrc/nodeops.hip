@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
                                                                const float *__restrict__ s,
                                                                const float *__restrict__ xres,
                                                                const float *__restrict__ pack, int64_t n_rows,
-                                                               float *__restrict__ out)
+                                                               float *__restrict__ out, int skew_mode)
 {
     __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
@@ -85,7 +85,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     const float eps = 1e-5f;
     Operand<SPLIT> op;
 
+    const Skew skew = make_skew<WAVES>(skew_mode, wave);
     stage_matrix<WAVES>(mats, buf0, wave, lane);
+    skew_begin(skew);
     // ---- gate: g = sigmoid(Wg [agg, xn] + bg)
     f32x16 va[4], acc[4];
     load_row(va, agg, rowc, h);
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     make_operand(op, va);
     sync_for_stage();
     gemm<WAVES>(acc, op, buf0, msc + 0, lane, mats + kMatFloats, buf1, wave);
+    skew_after_gemm(skew);
     {
         f32x16 vx[4];
         if (xn != nullptr) {
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         make_operand(op, vx);
         sync_for_stage();
         gemm<WAVES>(acc, op, buf1, msc + 2, lane, mats + 2 * kMatFloats, buf0, wave);
+        skew_after_gemm(skew);
     }
     // ---- u = agg + g * (s - agg)
     {
@@ -113,7 +117,12 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float g = 1.0f / (1.0f + expf(-acc[t][r]));
+                // sigmoid on the hardware exp2 / rcp (one Newton step on the reciprocal): ~2 ulp, a quarter of the
+                // instructions of expf + IEEE division
+                // (exponent clamped: den stays finite, so the Newton step never sees inf * 0)
+                const float den = 1.0f + __builtin_amdgcn_exp2f(fminf(acc[t][r] * -1.4426950408889634f, 126.0f));
+                float g = __builtin_amdgcn_rcpf(den);
+                g = fmaf(fmaf(-den, g, 1.0f), g, g);
                 va[t][r] = fmaf(g, vs[t][r] - va[t][r], va[t][r]);
             }
     }
@@ -122,6 +131,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     make_operand(op, va);
     sync_for_stage();
     gemm<WAVES>(acc, op, buf0, msc + 4, lane, mats + 3 * kMatFloats, buf1, wave);
+    skew_after_gemm(skew);
     layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
     f32x16 x1[4];
     load_row(x1, xres, rowc, h);
@@ -139,6 +149,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         load_feature_vec(acc, vec + kVB1 + hb * kC, h);
         sync_for_stage();
         gemm<WAVES>(acc, op, buf1, msc + 2 * (3 + 2 * hb), lane, w1 + kMatFloats, buf0, wave);
+        skew_after_gemm(skew);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -147,6 +158,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         make_operand(hid, acc);
         sync_for_stage();
         gemm<WAVES>(acc_o, hid, buf0, msc + 2 * (4 + 2 * hb), lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
+        skew_after_gemm(skew);
     }
     layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, h, eps);
     if (valid) {
@@ -155,6 +167,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         for (int t = 0; t < 4; ++t) acc_o[t] += x1[t];
         store_row(acc_o, out, row, h);
     }
+    skew_end(skew);
 }
 
 // A5 — MLPLayer heads (layers/mlp_layer.py:20-36: Linear(128,128) -> LayerNorm -> ReLU -> Linear(128,out)) of the decoder
@@ -171,7 +184,7 @@ struct MlpHeads {
 
 template <bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__restrict__ x, int64_t n_rows,
-                                                               const float *__restrict__ pack, MlpHeads hd)
+                                                               const float *__restrict__ pack, MlpHeads hd, int skew_mode)
 {
     __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
@@ -183,7 +196,9 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__re
     const float *vecs = pack + (size_t)n_mats * kMatFloats;
     const float *msc = vecs + hd.n_heads * kMlpVecs;
 
+    const Skew skew = make_skew<WAVES>(skew_mode, wave);
     stage_matrix<WAVES>(pack, wlds, wave, lane);
+    skew_begin(skew);
     f32x16 xv[4];
     load_row(xv, x, rowc, h);
     Operand<SPLIT> xo;
@@ -196,6 +211,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__re
         sync_for_stage();
         gemm<WAVES>(acc, xo, wlds + ((2 * i) & 1) * kMatVec4, msc + 4 * i, lane, pack + (size_t)(2 * i + 1) * kMatFloats,
                     wlds + ((2 * i + 1) & 1) * kMatVec4, wave);
+        skew_after_gemm(skew);
         layer_norm<true, true>(acc, vec + kC, vec + 2 * kC, h, 1e-5f);
         Operand<SPLIT> hid;
         make_operand(hid, acc);
@@ -204,6 +220,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__re
         gemm<WAVES>(acc, hid, wlds + ((2 * i + 1) & 1) * kMatVec4, msc + 4 * i + 2, lane,
                     2 * i + 2 < n_mats ? pack + (size_t)(2 * i + 2) * kMatFloats : nullptr, wlds + ((2 * i + 2) & 1) * kMatVec4,
                     wave);
+        skew_after_gemm(skew);
         if (valid) {
             const int od = hd.out_dim[i];
             float *y = hd.y[i] + row * od;
@@ -227,6 +244,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__re
                 }
         }
     }
+    skew_end(skew);
 }
 
 }  // namespace
@@ -254,8 +272,9 @@ extern "C" int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pa
     const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
     const int waves = pick_waves(n_rows, split);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    const int skew_mode = chain_skew_mode(0);
     void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * n_heads * 2 * 2.0 * kMatFloats, s);
-#define QCN_LAUNCH(S, W) hipLaunchKernelGGL((mlp_heads_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, pack, hd)
+#define QCN_LAUNCH(S, W) hipLaunchKernelGGL((mlp_heads_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, pack, hd, skew_mode)
     QCN_CHAIN_DISPATCH(split, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
@@ -299,10 +318,11 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
     const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
     const int waves = pick_waves(n_rows, split);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    const int skew_mode = chain_skew_mode(0);
     void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * kPostMats * 2.0 * kMatFloats, s);
 #define QCN_LAUNCH(S, W)                                                                                          \
     hipLaunchKernelGGL((attn_post_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, agg, xn_dst, s_proj, x_res, pack, n_rows, \
-                       out)
+                       out, skew_mode)
     QCN_CHAIN_DISPATCH(split, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;

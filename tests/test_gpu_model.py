@@ -47,6 +47,23 @@ def test_fourier_embedding_split_output_is_the_split_of_the_normalised_output():
     assert float((back - dense.double()).abs().max()) <= 2.0 ** -21 * float(dense.abs().max())
 
 
+def test_fourier_embedding_large_angles_vs_oracle():
+    """Angles beyond 2^15 rad leave the Cody-Waite fast path for the out-of-line ocml call (fourier.hip: sincos_large);
+    rows mix both paths, up to angles of ~1e9 rad where only a full Payne-Hanek reduction is right."""
+    m = randomize_(FourierEmbedding(input_dim=2, hidden_dim=128, num_freq_bands=64), seed=11).eval()
+    sd = cpu_state_dict(m)
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(300, 2, generator=gen) * 50.0
+    x[::3, 0] *= 1.0e4
+    x[1::7, 1] *= 1.0e7
+    want = oracle.fourier_embedding(sd, '', x, None)
+    ang = (x.unsqueeze(-1) * sd['freqs.weight'] * 2 * 3.141592653589793).abs()
+    assert float(ang.max()) > 1e8 and int((ang > 32768).sum()) > 1000 and int((ang < 32768).sum()) > 1000
+    with torch.no_grad():
+        got = m.to(DEV)(continuous_inputs=x.to(DEV), categorical_embs=None)
+    assert rel_err(got, want) < TOL
+
+
 @pytest.mark.parametrize('out_dim', [1, 40, 120])
 def test_mlp_layer_vs_reference_golden(out_dim):
     g = load_golden('ref_layers.npz')
