@@ -8,7 +8,8 @@ import os
 from ctypes import c_double, c_float, c_int, c_int64, c_size_t, c_void_p, POINTER
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libqcnet_hip.so')
+# QCN_HIP_LIB: load another build of the same library instead (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get('QCN_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libqcnet_hip.so')
 
 _lib = None
 

@@ -57,8 +57,11 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
                                                              const float *__restrict__ pack, float *__restrict__ y,
                                                              int64_t n_rows, int normalize_out, FourierTail tail, int skew_mode)
 {
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    // two matrix buffers + the per-feature vectors, in ONE __shared__ array (see attn_post_kernel)
+    constexpr int kVecBlock = IN * kDimVecs + kOutVecs + kScales;
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + kVecBlock / 4];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
+    float *const svec = reinterpret_cast<float *>(wlds + 2 * kMatVec4);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
@@ -66,13 +69,15 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     const int64_t rowc = valid ? row : n_rows - 1;   // tail lanes recompute the last row; their store is masked
     const float eps = 1e-5f;
     const float *mats = pack;
-    const float *vecs = pack + (size_t)(2 * IN + 1) * kMatFloats;
+    const float *vecs = svec;
     const float *out_vec = vecs + IN * kDimVecs;
     const float *msc = out_vec + kOutVecs;
     Operand<SPLIT> op;
 
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
     stage_matrix<WAVES>(mats, buf0, wave, lane);
+    stage_vectors<WAVES>(pack + (size_t)(2 * IN + 1) * kMatFloats, svec, kVecBlock, tid);
+    __syncthreads();
     skew_begin(skew);
 
     f32x16 acc_y[4];

@@ -13,6 +13,7 @@
 // four 128-wide blocks and never leaves the registers.  HBM traffic per row: reads of agg, xn, s, x and one write
 // (2.5 KiB) against 11 x 32 KiB of flops: MFMA-bound (fp32 matrix cores, exact fp32 fma chains).
 #include "chain_tile.hip.h"
+#include <cstdio>
 
 namespace {
 
@@ -64,6 +65,15 @@ constexpr int kVBg = 0, kVBout = kC, kVLpG = 2 * kC, kVLpB = 3 * kC, kVLfG = 4 *
               kVB2 = 10 * kC, kVLqG = 11 * kC, kVLqB = 12 * kC, kVPreG = 13 * kC, kVPreB = 14 * kC,
               kPostVecs = 15 * kC, kPostScales = 32;
 
+#ifdef QCN_CHAIN_STAMPS
+// diagnostic build only (scripts/dbg/build_variant.sh stamps -DQCN_CHAIN_STAMPS): cycles of block 0 / waves 0 and 4 per
+// phase class {epilogue + loads, barrier wait, GEMM}, read back and printed by the entry point
+__device__ unsigned long long g_post_stamps[2][4];
+#define PSTAMP(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); acc_t[k] += now_ - last_; last_ = now_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define PSTAMP(k)
+#endif
+
 template <bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__restrict__ agg,
                                                                const float *__restrict__ xn,
@@ -72,30 +82,38 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
                                                                const float *__restrict__ pack, int64_t n_rows,
                                                                float *__restrict__ out, int skew_mode)
 {
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + (kPostVecs + kPostScales) / 4];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
+    // (the vectors sit behind the two matrix buffers in ONE __shared__ array: with an array of their own hipcc's LDS-DMA
+    // alias tracking put a vmcnt(0) in front of every LDS read, the weight fragments of the GEMM loop included)
+    float *const svec = reinterpret_cast<float *>(wlds + 2 * kMatVec4);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
     const bool valid = row < n_rows;
     const int64_t rowc = valid ? row : n_rows - 1;
     const float *mats = pack;
-    const float *vec = pack + (size_t)kPostMats * kMatFloats;
+    const float *vec = svec;
     const float *msc = vec + kPostVecs;
     const float eps = 1e-5f;
     Operand<SPLIT> op;
 
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
+#ifdef QCN_CHAIN_STAMPS
+    unsigned long long acc_t[4] = {0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
     stage_matrix<WAVES>(mats, buf0, wave, lane);
+    stage_vectors<WAVES>(pack + (size_t)kPostMats * kMatFloats, svec, kPostVecs + kPostScales, tid);
+    __syncthreads();
     skew_begin(skew);
     // ---- gate: g = sigmoid(Wg [agg, xn] + bg)
     f32x16 va[4], acc[4];
     load_row(va, agg, rowc, h);
     load_feature_vec(acc, vec + kVBg, h);
     make_operand(op, va);
-    sync_for_stage();
+    PSTAMP(0) sync_for_stage(); PSTAMP(1)
     gemm<WAVES>(acc, op, buf0, msc + 0, lane, mats + kMatFloats, buf1, wave);
-    skew_after_gemm(skew);
+    skew_after_gemm(skew); PSTAMP(2)
     {
         f32x16 vx[4];
         if (xn != nullptr) {
@@ -105,9 +123,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
             layer_norm<true, false>(vx, vec + kVPreG, vec + kVPreB, h, eps);
         }
         make_operand(op, vx);
-        sync_for_stage();
+        PSTAMP(0) sync_for_stage(); PSTAMP(1)
         gemm<WAVES>(acc, op, buf1, msc + 2, lane, mats + 2 * kMatFloats, buf0, wave);
-        skew_after_gemm(skew);
+        skew_after_gemm(skew); PSTAMP(2)
     }
     // ---- u = agg + g * (s - agg)
     {
@@ -129,9 +147,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     // ---- x1 = x + LN_post(Wout u + bout); parked in `out` until the last residual
     load_feature_vec(acc, vec + kVBout, h);
     make_operand(op, va);
-    sync_for_stage();
+    PSTAMP(0) sync_for_stage(); PSTAMP(1)
     gemm<WAVES>(acc, op, buf0, msc + 4, lane, mats + 3 * kMatFloats, buf1, wave);
-    skew_after_gemm(skew);
+    skew_after_gemm(skew); PSTAMP(2)
     layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
     f32x16 x1[4];
     load_row(x1, xres, rowc, h);
@@ -147,18 +165,18 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     for (int hb = 0; hb < 4; ++hb) {
         const float *w1 = mats + (size_t)(3 + 2 * hb) * kMatFloats;
         load_feature_vec(acc, vec + kVB1 + hb * kC, h);
-        sync_for_stage();
+        PSTAMP(0) sync_for_stage(); PSTAMP(1)
         gemm<WAVES>(acc, op, buf1, msc + 2 * (3 + 2 * hb), lane, w1 + kMatFloats, buf0, wave);
-        skew_after_gemm(skew);
+        skew_after_gemm(skew); PSTAMP(2)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
         Operand<SPLIT> hid;
         make_operand(hid, acc);
-        sync_for_stage();
+        PSTAMP(0) sync_for_stage(); PSTAMP(1)
         gemm<WAVES>(acc_o, hid, buf0, msc + 2 * (4 + 2 * hb), lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
-        skew_after_gemm(skew);
+        skew_after_gemm(skew); PSTAMP(2)
     }
     layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, h, eps);
     if (valid) {
@@ -168,6 +186,11 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         store_row(acc_o, out, row, h);
     }
     skew_end(skew);
+#ifdef QCN_CHAIN_STAMPS
+    PSTAMP(0)
+    if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 4))
+        for (int c = 0; c < 4; ++c) g_post_stamps[wave >> 2][c] = acc_t[c];
+#endif
 }
 
 // A5 — MLPLayer heads (layers/mlp_layer.py:20-36: Linear(128,128) -> LayerNorm -> ReLU -> Linear(128,out)) of the decoder
@@ -186,18 +209,21 @@ template <bool SPLIT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__restrict__ x, int64_t n_rows,
                                                                const float *__restrict__ pack, MlpHeads hd, int skew_mode)
 {
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + (kMlpMaxHeads * kMlpVecs + kMlpScales) / 4];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
     const bool valid = row < n_rows;
     const int64_t rowc = valid ? row : n_rows - 1;
     const int n_mats = 2 * hd.n_heads;
-    const float *vecs = pack + (size_t)n_mats * kMatFloats;
+    float *const svec = reinterpret_cast<float *>(wlds + 2 * kMatVec4);
+    const float *vecs = svec;
     const float *msc = vecs + hd.n_heads * kMlpVecs;
 
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
     stage_matrix<WAVES>(pack, wlds, wave, lane);
+    stage_vectors<WAVES>(pack + (size_t)n_mats * kMatFloats, svec, hd.n_heads * kMlpVecs + kMlpScales, tid);
+    __syncthreads();
     skew_begin(skew);
     f32x16 xv[4];
     load_row(xv, x, rowc, h);
@@ -327,5 +353,15 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     qcn_prof_end(token, s);
+#ifdef QCN_CHAIN_STAMPS
+    {
+        unsigned long long h[2][4];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_post_stamps), sizeof(h));
+        for (int w = 0; w < 2; ++w)
+            printf("attn_post stamps wave %d (waves %d, rows %lld): epilogue+loads %llu, barrier %llu, gemm %llu cycles\n", 4 * w,
+                   waves, (long long)n_rows, h[w][0], h[w][1], h[w][2]);
+    }
+#endif
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }
