@@ -373,8 +373,10 @@ __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restri
 }
 
 // rows-per-block choice: WAVES waves x 32 rows.  A block always stages whole matrices, so fewer waves per block only
-// pays when the launch would otherwise leave CUs idle or the last round of blocks mostly empty.
-__host__ inline int pick_waves(int64_t n_rows, bool split, int n_cus = 256)
+// pays when the launch would otherwise leave CUs idle or the last round of blocks mostly empty.  `small_cost` = time of
+// a 4- (or 2-) wave block relative to an 8-wave block's 2.0, measured per kernel on one-round launches (MI355X, split
+// mode: attn_post 55 / 90 us, Fourier in = 3 43 / 57 us, ln_linear x4 33 / 50 us).
+__host__ inline int pick_waves(int64_t n_rows, bool split, double small_cost = 1.08, int n_cus = 256)
 {
     (void)split;
     if (const char *env = getenv("QCN_CHAIN_WAVES")) { const int w = atoi(env); if (w == 2 || w == 4 || w == 8) return w; }
@@ -383,7 +385,7 @@ __host__ inline int pick_waves(int64_t n_rows, bool split, int n_cus = 256)
     for (int w = 8; w >= 2; w >>= 1) {
         const int64_t blocks = (n_rows + 32 * w - 1) / (32 * w);
         const int64_t rounds = (blocks + n_cus - 1) / n_cus;
-        const double cost = (double)rounds * (w > 4 ? 2.0 : 1.08);   // 2 waves / SIMD hide the epilogues
+        const double cost = (double)rounds * (w > 4 ? 2.0 : small_cost);   // 2 waves / SIMD hide the epilogues
         if (cost < best_cost - 1e-9) { best_cost = cost; best = w; }
     }
     return best;

@@ -212,7 +212,7 @@ static int launch_fourier(const float *x, int input_dim, const float *extra, int
     if (extra_div < 1 || extra_div > 0x7fffffff) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
     const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
-    const int waves = pick_waves(n_rows, split);
+    const int waves = pick_waves(n_rows, split, 1.5);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
     const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC * (1 + tail.n_out));

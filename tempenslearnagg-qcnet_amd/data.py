@@ -44,6 +44,8 @@ class HeteroData:
 
     def __setitem__(self, key, value) -> None:
         self._stores[key] = value
+        self.__dict__.pop('_ready_event', None)      # a replaced store is new input: see mark_ready
+        self.__dict__.pop('_derived', None)
 
     def __contains__(self, key) -> bool:
         return key in self._stores
@@ -61,7 +63,7 @@ class HeteroData:
 
     def _map(self, fn):
         out = self.__class__.__new__(self.__class__)
-        out.__dict__.update({k: v for k, v in self.__dict__.items() if k != '_stores'})
+        out.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ('_stores', '_ready_event', '_derived')})
         out._stores = {}
         for key, store in self._stores.items():
             if isinstance(store, dict):
@@ -71,7 +73,39 @@ class HeteroData:
         return out
 
     def to(self, device, non_blocking: bool = False):
-        return self._map(lambda t: t.to(device, non_blocking=non_blocking))
+        out = self._map(lambda t: t.to(device, non_blocking=non_blocking))
+        if torch.device(device).type == 'cuda':
+            out.mark_ready()
+        return out
+
+    def mark_ready(self):
+        """Record, on the current stream, the point from which the inputs of this container are final.  The predictors'
+        preparation stream (utils/prep.py) then waits for THIS event instead of for everything enqueued on the main
+        stream, so the graph preparation of one batch overlaps the attention / MLP kernels of the previous batch.
+        ``to(device)`` records it (all tensors of the copy are new); whoever writes input tensors in place afterwards
+        (on any stream) must call ``mark_ready()`` again before the next ``predict``.  Containers without the mark are
+        handled conservatively (the preparation stream waits for the main stream)."""
+        dev = None
+        for store in self._stores.values():
+            for v in (store.values() if isinstance(store, dict) else (store,)):
+                if torch.is_tensor(v) and v.is_cuda:
+                    dev = v.device
+                    break
+            if dev is not None:
+                break
+        self.__dict__.pop('_derived', None)
+        if dev is None:
+            self.__dict__.pop('_ready_event', None)
+        else:
+            self._ready_event = torch.cuda.current_stream(dev).record_event()
+        return self
+
+    def derived(self, name: str, fn):
+        """Per-batch quantities computed from the inputs alone (e.g. the focal-track rows), computed once per container."""
+        cache = self.__dict__.setdefault('_derived', {})
+        if name not in cache:
+            cache[name] = fn()
+        return cache[name]
 
     def cpu(self):
         return self.to('cpu')

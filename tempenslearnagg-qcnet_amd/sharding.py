@@ -25,13 +25,33 @@ def batches(ids: Sequence[int], batch_size: int) -> List[List[int]]:
     return [list(ids[i:i + batch_size]) for i in range(0, len(ids), batch_size)]
 
 
+def focal_index(scenario_ids: Sequence[int], data) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(rows of the focal tracks, scenario ids as an fp32 column) of a batch.  Both need a host round trip (``nonzero``,
+    a host-to-device copy); they depend on the inputs alone, so they are made once per batch container and, on a GPU, on
+    the preparation stream: the host then never waits for the prediction kernels of the main stream and can enqueue the
+    next batch while this one runs."""
+    from .utils.prep import run_prep
+
+    def make():
+        category = data['agent']['category']
+        focal = (category == 3).nonzero(as_tuple=True)[0]
+        ids = torch.tensor(list(scenario_ids), dtype=torch.float32).to(category.device).unsqueeze(1)
+        return focal, ids
+
+    def cached():
+        return run_prep(data['agent']['category'].device, make)
+
+    key = ('focal', tuple(scenario_ids))
+    focal, ids = data.derived(key, cached) if hasattr(data, 'derived') else make()
+    assert focal.numel() == len(scenario_ids), 'expected exactly one focal track per scenario'
+    return focal, ids
+
+
 def focal_records(scenario_ids: Sequence[int], data, pred: Dict[str, torch.Tensor]) -> torch.Tensor:
     """One fp32 record per scenario: [scenario id, traj_refine[focal, :, :50, :2] (agent frame), softmax(pi)]."""
-    focal = (data['agent']['category'] == 3).nonzero(as_tuple=True)[0]
-    assert focal.numel() == len(scenario_ids), 'expected exactly one focal track per scenario'
+    focal, ids = focal_index(scenario_ids, data)
     traj = pred['traj_refine'][focal][..., :2].reshape(len(scenario_ids), -1)
     prob = pred['pi_softmax'][focal]
-    ids = torch.tensor(list(scenario_ids), dtype=torch.float32, device=traj.device).unsqueeze(1)
     return torch.cat([ids, traj.float(), prob.float()], dim=1)
 
 

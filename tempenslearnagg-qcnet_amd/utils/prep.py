@@ -23,7 +23,13 @@ _depth = 0
 def side_stream(device: torch.device) -> 'torch.cuda.Stream':
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _side:
-        _side[idx] = torch.cuda.Stream(device=device)
+        # lowest priority the runtime offers: the preparation kernels fill the CUs the main stream leaves idle instead of
+        # taking them from the attention / MLP kernels they overlap (QCN_PREP_PRIORITY overrides, 0 = same as main)
+        prio = int(os.environ.get('QCN_PREP_PRIORITY', '0'))
+        try:
+            _side[idx] = torch.cuda.Stream(device=device, priority=prio)
+        except (RuntimeError, ValueError):
+            _side[idx] = torch.cuda.Stream(device=device)
     return _side[idx]
 
 
@@ -53,11 +59,18 @@ def _record(obj, stream, seen) -> None:
                 _record(v, stream, seen)
 
 
-def inputs_ready(device: torch.device) -> None:
-    """Order the side stream after everything enqueued on the current stream so far (call once where fresh inputs
-    enter, e.g. at the top of ``predict``): sections started later may read those inputs."""
+def inputs_ready(device: torch.device, data=None) -> None:
+    """Order the side stream after the inputs (call once where fresh inputs enter, e.g. at the top of ``predict``):
+    sections started later may read them.  A container that carries a ready mark (``data.mark_ready()``, recorded by
+    ``data.to(device)``) is waited for by its event alone, so the preparation of this batch may overlap whatever the main
+    stream still runs for the previous one; without the mark the side stream waits for everything enqueued on the
+    current stream so far."""
     if ENABLED and device.type == 'cuda':
-        side_stream(device).wait_stream(torch.cuda.current_stream(device))
+        event = getattr(data, '_ready_event', None) if data is not None else None
+        if event is not None and os.environ.get('QCN_PREP_WAIT_MAIN', '0') == '0':
+            side_stream(device).wait_event(event)
+        else:
+            side_stream(device).wait_stream(torch.cuda.current_stream(device))
 
 
 def run_prep(device: torch.device, fn: Callable[[], object]):
