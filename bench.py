@@ -65,6 +65,8 @@ def main() -> None:
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg4', 'tiny'])
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-isolated-pass', action='store_true',
+                    help='skip the extra attention timing with the preparation stream off (roofline.isolated)')
     ap.add_argument('--no-exact-pass', action='store_true', help='skip the extra timing in the exact-fp32-MFMA mode')
     args = ap.parse_args()
 
@@ -114,6 +116,25 @@ def main() -> None:
         ops.prof_enable(False)
     launches, attn_ms, attn_bytes = ops.prof_collect(ops.PROF_ATTN_FUSED)
     ops.prof_collect(-1)
+
+    # The same launches with the preparation stream switched off (everything inline on one stream): in the timed region
+    # above the attention kernels share the CUs with the next batch's preparation kernels, which lengthens their
+    # individual durations while shortening the step; this pass times them alone on the GPU (kernel quality).
+    from tempenslearnagg_qcnet_amd.utils import prep as _prep
+    iso = None
+    if _prep.ENABLED and not args.no_isolated_pass:
+        _prep.ENABLED = False
+        with torch.no_grad(), torch.cuda.stream(main_stream):
+            model.predict(data)
+            torch.cuda.synchronize()
+            ops.prof_enable(True, kinds=[ops.PROF_ATTN_FUSED])
+            for _ in range(min(args.steps, 3)):
+                model.predict(data)
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+        iso = ops.prof_collect(ops.PROF_ATTN_FUSED)
+        ops.prof_collect(-1)
+        _prep.ENABLED = True
 
     # The same steps with the chain kernels in their exact-fp32-MFMA mode (include/qcnet_hip.h: QCN_MATMUL_EXACT_F32),
     # reported beside `value` (which is measured in the default split-f16 mode, whose matmul error is not larger).
@@ -166,7 +187,12 @@ def main() -> None:
                          'launches': launches, 'avg_launch_us': attn_ms * 1e3 / max(launches, 1),
                          'alg_bytes_per_launch': attn_bytes / max(launches, 1),
                          'formula': '1552*E + 1024*n_dst (SURVEY 8(d), r-projection fused) with E = the edges a launch processes: a mode-replicated '
-                                    'relation is processed once per base edge for all K modes; traffic = HBM bytes per launch (PMC)', 'traffic': traffic},
+                                    'relation is processed once per base edge for all K modes; traffic = HBM bytes per launch (PMC); '
+                                    'isolated = the same launches timed with the preparation stream off (in the timed region they share '
+                                    'the CUs with the next batch\'s preparation kernels)', 'traffic': traffic,
+                         'isolated': None if iso is None or iso[1] <= 0 else
+                         {'achieved': iso[2] / (iso[1] * 1e-3) / 1e9, 'frac': iso[2] / (iso[1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          'launches': iso[0], 'avg_launch_us': iso[1] * 1e3 / max(iso[0], 1)}},
             'exact_f32_mfma': None if exact_ms is None else
             {'ms_per_step': exact_ms, 'value': batch_size / (exact_ms * 1e-3), 'unit': 'scenarios/sec',
              'max_rel_diff_loc_refine_pos': float((pred_exact['loc_refine_pos'] - pred['loc_refine_pos']).abs().max()
