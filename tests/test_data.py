@@ -86,3 +86,26 @@ def test_pack_chain_matrix_is_a_permutation_that_keeps_the_linear_map():
     xin = x[order].double().view(8, 8, 2).permute(0, 2, 1)                           # [j, h, i]
     ys = torch.einsum('jthmi,jhi->mt', wsum, xin)
     assert torch.allclose(ys, ref, rtol=0, atol=float(w.abs().max()) * float(x.abs().sum()) * 2.0 ** -21)
+
+
+def test_ready_mark_and_derived_cache_follow_the_container():
+    """data.mark_ready / data.derived (data.py): per-container state that copies do not inherit and that replacing a
+    store drops; on the CPU there is no event to record."""
+    from tempenslearnagg_qcnet_amd.data import Batch
+    from tempenslearnagg_qcnet_amd import sharding
+    from tempenslearnagg_qcnet_amd.synthetic import config_scene, make_batch
+    cfg = config_scene('tiny')
+    batch = make_batch([0, 1], **cfg['scene'])
+    assert isinstance(batch, Batch)
+    calls = []
+    assert batch.derived('k', lambda: calls.append(1) or 7) == 7
+    assert batch.derived('k', lambda: calls.append(1) or 8) == 7 and len(calls) == 1
+    copy = batch.clone()
+    assert '_derived' not in copy.__dict__ and getattr(copy, '_ready_event', None) is None
+    batch.mark_ready()                                   # CPU tensors: nothing to record, derived values dropped
+    assert getattr(batch, '_ready_event', None) is None and '_derived' not in batch.__dict__
+    focal, ids = sharding.focal_index([0, 1], batch)
+    assert focal.numel() == 2 and ids.shape == (2, 1) and ids[:, 0].tolist() == [0.0, 1.0]
+    assert sharding.focal_index([0, 1], batch)[0] is focal          # once per container
+    batch['agent'] = dict(batch['agent'])                # a replaced store is new input
+    assert '_derived' not in batch.__dict__

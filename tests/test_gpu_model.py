@@ -188,6 +188,55 @@ def test_fast_path_switches_do_not_change_predictions():
         assert rel_err(first[k], fused[k]) < 1e-5, k
 
 
+def test_back_to_back_batches_overlap_without_changing_predictions():
+    """Cross-batch overlap (utils/prep.py: the preparation stream waits for a batch's ready mark, not for the main
+    stream): different batches predicted back to back without any host synchronisation, at a size whose kernels run long
+    enough to overlap the next batch's preparation, equal their isolated predictions bit for bit; so does a container that
+    was modified in place and re-marked, and the per-batch focal records (sharding.focal_index on the preparation stream)."""
+    from tempenslearnagg_qcnet_amd import sharding
+    cfg = config_scene('cfg3')
+    model = _model(cfg, seed=9).to(DEV)
+    id_sets = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11]]
+    batches = [make_batch(ids, **cfg['scene']).to(DEV) for ids in id_sets]
+    assert all(getattr(b, '_ready_event', None) is not None for b in batches)
+    keys = ('traj_refine', 'pi_softmax')
+    with torch.no_grad():
+        alone = []
+        for ids, b in zip(id_sets, batches):
+            p = model.predict(b)
+            rec = sharding.focal_records(ids, b, p)
+            torch.cuda.synchronize()
+            alone.append(({k: p[k].clone() for k in keys}, rec.clone()))
+        order = [0, 1, 2, 1, 0, 2, 2, 0]
+        runs = []
+        for i in order:                                   # no synchronisation inside this loop
+            p = model.predict(batches[i])
+            runs.append((i, p, sharding.focal_records(id_sets[i], batches[i], p)))
+        torch.cuda.synchronize()
+        for i, p, rec in runs:
+            for k in keys:
+                assert torch.equal(p[k], alone[i][0][k]), (i, k)
+            assert torch.equal(rec, alone[i][1]), i
+        # inputs rewritten in place on the main stream, then re-marked: the preparation must see the new values
+        b = batches[0]
+        b['agent']['position'].copy_(batches[1]['agent']['position'])
+        b['agent']['heading'].copy_(batches[1]['agent']['heading'])
+        b['agent']['velocity'].copy_(batches[1]['agent']['velocity'])
+        b['agent']['valid_mask'].copy_(batches[1]['agent']['valid_mask'])
+        b['agent']['predict_mask'].copy_(batches[1]['agent']['predict_mask'])
+        b.mark_ready()
+        moved = model.predict(b)
+        fresh = make_batch(id_sets[0], **cfg['scene']).to(DEV)
+        for name in ('position', 'heading', 'velocity', 'valid_mask', 'predict_mask'):
+            fresh['agent'][name] = batches[1]['agent'][name].clone()
+        assert getattr(fresh, '_ready_event', None) is not None     # store entries may be replaced; stores may not
+        fresh.mark_ready()
+        want = model.predict(fresh)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(moved[k], want[k]), k
+
+
 def test_ragged_batch_with_dead_agents_vs_oracle():
     """Ragged inputs: scenarios of different agent / polygon counts in one batch, one agent that is never valid, one
     that is valid in the history but not predicted, and one scenario with a single polygon — the full ten-frame pass
