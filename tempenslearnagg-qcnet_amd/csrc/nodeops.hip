@@ -114,12 +114,22 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     PSTAMP(0) sync_for_stage(); PSTAMP(1)
     gemm<WAVES>(acc, op, buf0, msc + 0, lane, mats + kMatFloats, buf1, wave);
     skew_after_gemm(skew); PSTAMP(2)
+    // Blocks of up to four waves (one wave per SIMD, 512 registers): x_res is read ONCE and x1 is never parked in `out` —
+    // a row the lane reads back is a scattered load (32 lines of 32 B per instruction) with its latency exposed (−5 % at
+    // 96 000 rows).  Eight-wave blocks (256 registers) keep the read-back: held in registers there, the two row vectors
+    // become 250 spilled registers and cost more than the loads they save (+3-6 %).
+    constexpr bool kKeepRows = WAVES <= 4;
+    f32x16 xr[4];
     {
         f32x16 vx[4];
         if (xn != nullptr) {
             load_row(vx, xn, rowc, h);
         } else {   // xn = attn_prenorm_x_dst(x): recomputed (same arithmetic as qcn_ln_linear_f32) instead of a round trip
             load_row(vx, xres, rowc, h);
+            if constexpr (kKeepRows) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) xr[t] = vx[t];
+            }
             layer_norm<true, false>(vx, vec + kVPreG, vec + kVPreB, h, eps);
         }
         make_operand(op, vx);
@@ -144,21 +154,22 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
                 va[t][r] = fmaf(g, vs[t][r] - va[t][r], va[t][r]);
             }
     }
-    // ---- x1 = x + LN_post(Wout u + bout); parked in `out` until the last residual
+    // ---- x1 = x + LN_post(Wout u + bout)
     load_feature_vec(acc, vec + kVBout, h);
     make_operand(op, va);
     PSTAMP(0) sync_for_stage(); PSTAMP(1)
     gemm<WAVES>(acc, op, buf0, msc + 4, lane, mats + 3 * kMatFloats, buf1, wave);
     skew_after_gemm(skew); PSTAMP(2)
     layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
-    f32x16 x1[4];
-    load_row(x1, xres, rowc, h);
+    if (!kKeepRows || xn != nullptr) load_row(xr, xres, rowc, h);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) x1[t] += acc[t];
-    if (valid) store_row(x1, out, row, h);
+    for (int t = 0; t < 4; ++t) xr[t] += acc[t];           // x1
+    if constexpr (!kKeepRows) { if (valid) store_row(xr, out, row, h); }   // parked in `out` until the last residual
     // ---- feed-forward block, hidden layer in four 128-wide blocks
-    layer_norm<true, false>(x1, vec + kVLfG, vec + kVLfB, h, eps);
-    make_operand(op, x1);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = xr[t];
+    layer_norm<true, false>(acc, vec + kVLfG, vec + kVLfB, h, eps);
+    make_operand(op, acc);
     f32x16 acc_o[4];
     load_feature_vec(acc_o, vec + kVB2, h);
 #pragma unroll 1
@@ -180,9 +191,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     }
     layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, h, eps);
     if (valid) {
-        load_row(x1, out, row, h);   // the lane's own earlier store
+        if constexpr (!kKeepRows) load_row(xr, out, row, h);   // the lane's own earlier store
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc_o[t] += x1[t];
+        for (int t = 0; t < 4; ++t) acc_o[t] += xr[t];
         store_row(acc_o, out, row, h);
     }
     skew_end(skew);
