@@ -304,6 +304,118 @@ __device__ __forceinline__ void store_row(const f32x16 (&v)[4], float *__restric
         }
 }
 
+// Coalesced row I/O through a per-wave LDS transposition block (4 KiB = the wave's 32 rows x one 32-feature block).
+// load_row / store_row let every lane touch its own 512-B row: one instruction = 32 lines of 32 B.  Here a global
+// instruction covers 8 rows x 128 B (full lines: lane L -> row 8 i + (L >> 3), 16-B chunk L & 7) and the lane-owns-row
+// register layout is produced by the LDS: chunk c of row n sits at chunk position c ^ ((n >> 1) & 7) of the row's
+// 128 bytes, which makes both the row-major writes and the (row n, chunks 2 q + h) reads conflict-free.  DS operations
+// of one wave execute in order, so no barrier is needed between the two halves.
+// `row0` = first row of the wave's tile; rows >= n_rows are clamped on load and masked on store.
+__device__ __forceinline__ void load_tile(f32x16 (&v)[4], const float *__restrict__ src, int64_t row0, int64_t n_rows,
+                                          f32x4 *xpose, int lane)
+{
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f32x4 g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3), c = lane & 7;
+            int64_t row = row0 + r;
+            row = row < n_rows ? row : n_rows - 1;
+            g[i] = *reinterpret_cast<const f32x4 *>(src + row * kC + 32 * t + 4 * c);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3), c = lane & 7;
+            xpose[r * 8 + (c ^ ((r >> 1) & 7))] = g[i];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 x = xpose[n * 8 + ((2 * q + h) ^ ((n >> 1) & 7))];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[t][4 * q + j] = x[j];
+        }
+    }
+}
+
+__device__ __forceinline__ void store_tile(const f32x16 (&v)[4], float *__restrict__ dst, int64_t row0, int64_t n_rows,
+                                           f32x4 *xpose, int lane)
+{
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = v[t][4 * q + j];
+            xpose[n * 8 + ((2 * q + h) ^ ((n >> 1) & 7))] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3), c = lane & 7;
+            const f32x4 x = xpose[r * 8 + (c ^ ((r >> 1) & 7))];
+            if (row0 + r < n_rows) *reinterpret_cast<f32x4 *>(dst + (row0 + r) * kC + 32 * t + 4 * c) = x;
+        }
+    }
+}
+
+// The same with a 2 KiB block per wave (32 rows x 16 features: half a feature block per pass) for the kernels whose
+// per-feature vectors leave less than 4 KiB per wave: a global instruction covers 16 rows x 64 B (lane L -> row
+// 16 i + (L >> 2), chunk L & 3), chunk c of row n sits at chunk position c ^ ((n >> 2) & 3) of the row's 64 bytes.
+__device__ __forceinline__ void load_tile2(f32x16 (&v)[4], const float *__restrict__ src, int64_t row0, int64_t n_rows,
+                                           f32x4 *xpose, int lane)
+{
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp) {           // pass = (feature block t, half)
+        const int t = tp >> 1, half = tp & 1;
+        f32x4 g[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 16 * i + (lane >> 2), c = lane & 3;
+            int64_t row = row0 + r;
+            row = row < n_rows ? row : n_rows - 1;
+            g[i] = *reinterpret_cast<const f32x4 *>(src + row * kC + 32 * t + 16 * half + 4 * c);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 16 * i + (lane >> 2), c = lane & 3;
+            xpose[r * 4 + (c ^ ((r >> 2) & 3))] = g[i];
+        }
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            const f32x4 x = xpose[n * 4 + ((2 * qq + h) ^ ((n >> 2) & 3))];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[t][4 * (2 * half + qq) + j] = x[j];
+        }
+    }
+}
+
+__device__ __forceinline__ void store_tile2(const f32x16 (&v)[4], float *__restrict__ dst, int64_t row0, int64_t n_rows,
+                                            f32x4 *xpose, int lane)
+{
+    const int n = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int tp = 0; tp < 8; ++tp) {
+        const int t = tp >> 1, half = tp & 1;
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+            f32x4 x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = v[t][4 * (2 * half + qq) + j];
+            xpose[n * 4 + ((2 * qq + h) ^ ((n >> 2) & 3))] = x;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 16 * i + (lane >> 2), c = lane & 3;
+            const f32x4 x = xpose[r * 4 + (c ^ ((r >> 2) & 3))];
+            if (row0 + r < n_rows) *reinterpret_cast<f32x4 *>(dst + (row0 + r) * kC + 32 * t + 16 * half + 4 * c) = x;
+        }
+    }
+}
+
 // The row as split f16 (the operand format of qcn_attn_modes_f32, see qcn_split_rows_f16): dst row = [hi 128 | lo 128]
 // with hi + lo = v * scale
 __device__ __forceinline__ void store_row_split(const f32x16 (&v)[4], _Float16 *__restrict__ dst, int64_t row, int h, float scale)

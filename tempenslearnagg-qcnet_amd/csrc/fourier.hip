@@ -59,9 +59,10 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 {
     // two matrix buffers + the per-feature vectors, in ONE __shared__ array (see attn_post_kernel)
     constexpr int kVecBlock = IN * kDimVecs + kOutVecs + kScales;
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + kVecBlock / 4];
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + kVecBlock / 4 + WAVES * 128];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
     float *const svec = reinterpret_cast<float *>(wlds + 2 * kMatVec4);
+    f32x4 *const xpose = wlds + 2 * kMatVec4 + kVecBlock / 4 + (threadIdx.x >> 6) * 128;   // store_tile2: coalesced row stores
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
@@ -171,11 +172,10 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
     skew_after_gemm(skew);
     if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
+    const int64_t row0 = row - (lane & 31);
     if (tail.n_out == 0) {
-        if (valid) {
-            if (normalize_out == 2) store_row_split(acc_o, reinterpret_cast<_Float16 *>(y), row, h, 2048.0f);
-            else store_row(acc_o, y, row, h);
-        }
+        if (normalize_out == 2) { if (valid) store_row_split(acc_o, reinterpret_cast<_Float16 *>(y), row, h, 2048.0f); }
+        else store_tile2(acc_o, y, row0, n_rows, xpose, lane);
         skew_end(skew);
         return;
     }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         gemm<WAVES>(acc, op, wlds + ((j + 1) & 1) * kMatVec4, tsc + 2 * j, lane,
                     j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr, wlds + (j & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
-        if (valid) store_row(acc, tail.y[j], row, h);
+        store_tile2(acc, tail.y[j], row0, n_rows, xpose, lane);
     }
     skew_end(skew);
 }

@@ -29,18 +29,18 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
                                                                float *__restrict__ y2, float *__restrict__ y3,
                                                                float *__restrict__ xn_out)
 {
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4];
+    // two matrix buffers + one 4 KiB transposition block per wave (load_tile / store_tile), in ONE __shared__ array
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + WAVES * 256];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
-    const bool valid = row < n_rows;
-    const int64_t rowc = valid ? row : n_rows - 1;
+    const int64_t row0 = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave;
+    f32x4 *const xpose = wlds + 2 * kMatVec4 + wave * 256;
 
     stage_matrix<WAVES>(wp, wlds, wave, lane);
     f32x16 xv[4];
-    load_row(xv, x, rowc, h);
+    load_tile(xv, x, row0, n_rows, xpose, lane);
     if (ln_g != nullptr) layer_norm<true, false>(xv, ln_g, ln_b, h, 1e-5f);
-    if (xn_out != nullptr && valid) store_row(xv, xn_out, row, h);
+    if (xn_out != nullptr) store_tile(xv, xn_out, row0, n_rows, xpose, lane);
     const float *mscale = wp + (size_t)n_out * kMatFloats;   // {scale, 1 / scale} per matrix
     Operand<SPLIT> xo;
     make_operand(xo, xv);
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
         gemm<WAVES>(acc, xo, wlds + (j & 1) * kMatVec4, mscale + 2 * j, lane,
                     j + 1 < n_out ? wp + (size_t)(j + 1) * kMatFloats : nullptr, wlds + ((j + 1) & 1) * kMatVec4, wave);
         float *y = j == 0 ? y0 : j == 1 ? y1 : j == 2 ? y2 : y3;
-        if (valid) store_row(acc, y, row, h);
+        store_tile(acc, y, row0, n_rows, xpose, lane);
     }
 }
 
@@ -82,16 +82,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
                                                                const float *__restrict__ pack, int64_t n_rows,
                                                                float *__restrict__ out, int skew_mode)
 {
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + (kPostVecs + kPostScales) / 4];
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + (kPostVecs + kPostScales) / 4 + WAVES * 128];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
     // (the vectors sit behind the two matrix buffers in ONE __shared__ array: with an array of their own hipcc's LDS-DMA
     // alias tracking put a vmcnt(0) in front of every LDS read, the weight fragments of the GEMM loop included)
     float *const svec = reinterpret_cast<float *>(wlds + 2 * kMatVec4);
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
-    const bool valid = row < n_rows;
-    const int64_t rowc = valid ? row : n_rows - 1;
+    const int64_t row0 = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave;
+    f32x4 *const xpose = wlds + 2 * kMatVec4 + (kPostVecs + kPostScales) / 4 + wave * 128;   // load_tile2 / store_tile2
     const float *mats = pack;
     const float *vec = svec;
     const float *msc = vec + kPostVecs;
@@ -108,7 +107,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     skew_begin(skew);
     // ---- gate: g = sigmoid(Wg [agg, xn] + bg)
     f32x16 va[4], acc[4];
-    load_row(va, agg, rowc, h);
+    load_tile2(va, agg, row0, n_rows, xpose, lane);
     load_feature_vec(acc, vec + kVBg, h);
     make_operand(op, va);
     PSTAMP(0) sync_for_stage(); PSTAMP(1)
@@ -123,9 +122,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     {
         f32x16 vx[4];
         if (xn != nullptr) {
-            load_row(vx, xn, rowc, h);
+            load_tile2(vx, xn, row0, n_rows, xpose, lane);
         } else {   // xn = attn_prenorm_x_dst(x): recomputed (same arithmetic as qcn_ln_linear_f32) instead of a round trip
-            load_row(vx, xres, rowc, h);
+            load_tile2(vx, xres, row0, n_rows, xpose, lane);
             if constexpr (kKeepRows) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) xr[t] = vx[t];
@@ -140,7 +139,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     // ---- u = agg + g * (s - agg)
     {
         f32x16 vs[4];
-        load_row(vs, s, rowc, h);
+        load_tile2(vs, s, row0, n_rows, xpose, lane);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -161,10 +160,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     gemm<WAVES>(acc, op, buf0, msc + 4, lane, mats + 3 * kMatFloats, buf1, wave);
     skew_after_gemm(skew); PSTAMP(2)
     layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
-    if (!kKeepRows || xn != nullptr) load_row(xr, xres, rowc, h);
+    if (!kKeepRows || xn != nullptr) load_tile2(xr, xres, row0, n_rows, xpose, lane);
 #pragma unroll
     for (int t = 0; t < 4; ++t) xr[t] += acc[t];           // x1
-    if constexpr (!kKeepRows) { if (valid) store_row(xr, out, row, h); }   // parked in `out` until the last residual
+    if constexpr (!kKeepRows) store_tile2(xr, out, row0, n_rows, xpose, lane);   // parked in `out` until the last residual
     // ---- feed-forward block, hidden layer in four 128-wide blocks
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = xr[t];
@@ -190,12 +189,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         skew_after_gemm(skew); PSTAMP(2)
     }
     layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, h, eps);
-    if (valid) {
-        if constexpr (!kKeepRows) load_row(xr, out, row, h);   // the lane's own earlier store
+    if constexpr (!kKeepRows) load_tile2(xr, out, row0, n_rows, xpose, lane);   // the wave's own earlier store
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc_o[t] += xr[t];
-        store_row(acc_o, out, row, h);
-    }
+    for (int t = 0; t < 4; ++t) acc_o[t] += xr[t];
+    store_tile2(acc_o, out, row0, n_rows, xpose, lane);
     skew_end(skew);
 #ifdef QCN_CHAIN_STAMPS
     PSTAMP(0)
