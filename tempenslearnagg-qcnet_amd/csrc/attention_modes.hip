@@ -192,6 +192,44 @@ __device__ __forceinline__ int rowptr_at(const ModesArgs &a, int row)
     return *((cint *)(uintptr_t)a.rowptr + row);
 }
 
+// smallest r in [0, n_rows] with rowptr[r] >= target (rowptr non-decreasing, rowptr[n_rows] >= target): a 64-ary search,
+// every lane probes one row per round (three rounds for 16 000 rows)
+__device__ __forceinline__ int rowptr_lower_bound(const int32_t *rowptr, int n_rows, int target, int lane)
+{
+    int lo = 0, hi = n_rows;                                   // the answer lies in [lo, hi]
+    while (lo < hi) {
+        const int step = (hi - lo + 63) / 64;
+        const int p = min(lo + lane * step, hi);
+        const unsigned long long m = __ballot(rowptr[p] >= target);    // monotone in the lane index
+        if (m == 0) {
+            lo = min(lo + 63 * step, hi) + 1;                  // beyond the last probe (which is < hi: rowptr[hi] >= target)
+        } else {
+            const int first = __ffsll((long long)m) - 1;
+            const int new_lo = first == 0 ? lo : min(lo + (first - 1) * step, hi) + 1;
+            hi = min(lo + first * step, hi);
+            lo = new_lo;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(lo);
+}
+
+// Contiguous chunk of CSR rows of logical block lb out of nb: chunks of equal EDGE count (block lb takes the rows whose
+// first edge lies in [lb E / nb, (lb + 1) E / nb)) — with equal row counts the fullest of 256 chunks of the cfg3 decoder
+// relations carries 9-11 % more tiles than the average and the launch waits for it; balanced, 1-2 %.
+__device__ __forceinline__ void row_chunk(const int32_t *rowptr, int n_rows, int lb, int nb, int lane, int *row_begin, int *row_end)
+{
+    using cint = const __attribute__((address_space(4))) int32_t;
+    const int num_edges = *((cint *)(uintptr_t)rowptr + n_rows);
+    if (num_edges <= 0) {
+        const int per = (n_rows + nb - 1) / nb;
+        *row_begin = min(lb * per, n_rows);
+        *row_end = min(*row_begin + per, n_rows);
+        return;
+    }
+    *row_begin = lb == 0 ? 0 : rowptr_lower_bound(rowptr, n_rows, (int)((long long)lb * num_edges / nb), lane);
+    *row_end = lb + 1 >= nb ? n_rows : rowptr_lower_bound(rowptr, n_rows, (int)((long long)(lb + 1) * num_edges / nb), lane);
+}
+
 // first tile of the first non-empty row in [row, row_end)
 __device__ __forceinline__ Tile first_tile(const ModesArgs &a, int row, int row_end)
 {
@@ -277,11 +315,11 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i = lane & 15, g = lane >> 4;
 
-    // contiguous chunk of CSR rows per workgroup (XCD-contiguous through the block remap)
+    // contiguous, edge-balanced chunk of CSR rows per workgroup (XCD-contiguous through the block remap)
     const int nb = gridDim.x;
     const int lb = qcn_xcd_remap(blockIdx.x, gridDim.x);
-    const int per = (a.n_rows + nb - 1) / nb;
-    const int row_begin = min(lb * per, a.n_rows), row_end = min(row_begin + per, a.n_rows);
+    int row_begin, row_end;
+    row_chunk(a.rowptr, a.n_rows, lb, nb, lane, &row_begin, &row_end);
 
     // the head's weight fragments: frag[lane][j] = W[16 w + (lane & 15)][32 ks + 8 (lane >> 4) + j]
     half8 wk_hi[4], wk_lo[4], wv_hi[4], wv_lo[4];
@@ -524,8 +562,8 @@ __global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesAr
 
     const int nb = gridDim.x;
     const int lb = qcn_xcd_remap(blockIdx.x, gridDim.x);
-    const int per = (a.n_rows + nb - 1) / nb;
-    const int row_begin = min(lb * per, a.n_rows), row_end = min(row_begin + per, a.n_rows);
+    int row_begin, row_end;
+    row_chunk(a.rowptr, a.n_rows, lb, nb, lane, &row_begin, &row_end);
 
     half8 wk_hi[4], wk_lo[4], wv_hi[4], wv_lo[4];
 #pragma unroll
@@ -709,7 +747,9 @@ extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v
     (void)hipMemsetAsync(d_stamps, 0, 64 * sizeof(unsigned long long), qcn_stream(stream));
     args.stamps = d_stamps;
 #endif
-    int per_cu = 2;
+    // one workgroup per CU (the LDS ring admits only one at a time anyway): with two contiguous row chunks per CU the second
+    // prologue / pipeline fill costs more than the finer partition returns (isolated attention roofline 0.497 -> 0.523)
+    int per_cu = 1;
     if (const char *env = getenv("QCN_MODES_WG_PER_CU")) { const int want = atoi(env); if (want >= 1 && want <= 8) per_cu = want; }
     int64_t grid = n_rows < 256 * per_cu ? n_rows : 256 * per_cu;
     hipStream_t s = qcn_stream(stream);
