@@ -60,8 +60,8 @@ def cpu_baseline(hparams, scene, state_dict, sample_scenarios: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg4', 'tiny'])
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
