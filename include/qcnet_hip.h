@@ -195,6 +195,15 @@ int qcn_fourier_linear_f32(const float *x, int input_dim, const float *extra, in
                            const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
                            float *y0, float *y1, float *y2, void *stream);
 
+/* The same chain with the embedding's last Linear (to_out.2, layers/fourier_embedding.py:42-46,67) folded into the layers
+ * that follow it: there is no non-linearity between to_out.2 and W_j, so the caller passes W'_j = W_j W_out and
+ * b'_j = W_j b_out + b_j (products formed in fp64) and the kernel applies them to relu(LN(sum)) directly — one GEMM per
+ * row less.  input_dim >= 1.  No counterpart in the reference (it runs the two Linear layers one after the other,
+ * modules/qcnet_decoder.py:255-257); results differ from qcn_fourier_linear_f32 by fp32 rounding only. */
+int qcn_fourier_folded_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
+                                  const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
+                                  float *y0, float *y1, float *y2, void *stream);
+
 /* A2 node side (K5/K6 of SURVEY.md §2b fused) — xn = LayerNorm(x) (skipped when ln_weight == NULL);
  * y_j = W_j xn + b_j for j < n_out <= 4 (the to_q / to_k / to_v / to_s projections of one AttentionLayer call,
  * layers/attention_layer.py:74-79,115-117,108).  x, y_j, xn_out: [n_rows,128]; wt: n_out chain-packed matrices

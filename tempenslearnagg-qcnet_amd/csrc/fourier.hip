@@ -49,6 +49,7 @@ struct FourierTail {
     const float *bias;    // [n_out, 128] or nullptr
     float *y[3];
     int n_out;            // 0: store the embedding itself
+    int fold;             // 1: the caller folded to_out's Linear into wt / bias (y_j = W'_j relu(LN(sum)) + b'_j): one GEMM less
 };
 
 template <int IN, bool SPLIT, int WAVES>
@@ -152,7 +153,8 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
             }
         make_operand(op, acc_h);
         sync_for_stage();
-        gemm<WAVES>(acc_y, op, buf1, msc + 4 * d + 2, lane, mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
+        gemm<WAVES>(acc_y, op, buf1, msc + 4 * d + 2, lane,
+                    tail.fold && d == IN - 1 ? tail.wt : mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
         skew_after_gemm(skew);
     }
 
@@ -165,22 +167,26 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 
     // ---- to_out: LN -> ReLU -> Linear (:67)
     layer_norm<true, true>(acc_y, out_vec + kVOutG, out_vec + kVOutBe, h, eps);
-    f32x16 acc_o[4];
-    load_feature_vec(acc_o, out_vec + kVOutB, h);
     make_operand(op, acc_y);
-    sync_for_stage();
-    gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
-    skew_after_gemm(skew);
-    if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
     const int64_t row0 = row - (lane & 31);
-    if (tail.n_out == 0) {
-        if (normalize_out == 2) { if (valid) store_row_split(acc_o, reinterpret_cast<_Float16 *>(y), row, h, 2048.0f); }
-        else store_tile2(acc_o, y, row0, n_rows, xpose, lane);
-        skew_end(skew);
-        return;
+    if (!tail.fold) {
+        f32x16 acc_o[4];
+        load_feature_vec(acc_o, out_vec + kVOutB, h);
+        sync_for_stage();
+        gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
+        skew_after_gemm(skew);
+        if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
+        if (tail.n_out == 0) {
+            if (normalize_out == 2) { if (valid) store_row_split(acc_o, reinterpret_cast<_Float16 *>(y), row, h, 2048.0f); }
+            else store_tile2(acc_o, y, row0, n_rows, xpose, lane);
+            skew_end(skew);
+            return;
+        }
+        make_operand(op, acc_o);
     }
-    // ---- tail: the embedding is the operand of n_out more layers (matrix j sits in buffer (j + 1) & 1)
-    make_operand(op, acc_o);
+    // ---- tail: the embedding (folded: its last hidden vector) is the operand of n_out more layers; matrix j sits in
+    // buffer (j + 1) & 1 behind to_out's matrix, in buffer j & 1 when that GEMM is folded away
+    const int first_buf = tail.fold ? 0 : 1;
     const float *tsc = tail.wt + (size_t)tail.n_out * kMatFloats;
 #pragma unroll 1
     for (int j = 0; j < tail.n_out; ++j) {
@@ -188,8 +194,9 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         if (tail.bias != nullptr) load_feature_vec(acc, tail.bias + j * kC, h);
         else fill_zero(acc);
         sync_for_stage();
-        gemm<WAVES>(acc, op, wlds + ((j + 1) & 1) * kMatVec4, tsc + 2 * j, lane,
-                    j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr, wlds + (j & 1) * kMatVec4, wave);
+        gemm<WAVES>(acc, op, wlds + ((j + first_buf) & 1) * kMatVec4, tsc + 2 * j, lane,
+                    j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr,
+                    wlds + ((j + first_buf + 1) & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
         store_tile2(acc, tail.y[j], row0, n_rows, xpose, lane);
     }
@@ -215,7 +222,7 @@ static int launch_fourier(const float *x, int input_dim, const float *extra, int
     const int waves = pick_waves(n_rows, split, 1.5);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
-    const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC * (1 + tail.n_out));
+    const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC * (1 - tail.fold + tail.n_out));
     void *token = qcn_prof_begin(QCN_PROF_FOURIER, flops, s);
 #define QCN_LAUNCH(S, W)                                                                                           \
     hipLaunchKernelGGL((fourier_kernel<QCN_IN, S, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, \
@@ -255,6 +262,16 @@ extern "C" int qcn_fourier_linear_f32(const float *x, int input_dim, const float
                                       float *y0, float *y1, float *y2, void *stream)
 {
     if (n_out < 1 || n_out > 3 || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
-    FourierTail tail{wt, bias, {y0, y1, y2}, n_out};
+    FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 0};
+    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, stream);
+}
+
+extern "C" int qcn_fourier_folded_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
+                                             const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
+                                             float *y0, float *y1, float *y2, void *stream)
+{
+    if (n_out < 1 || n_out > 3 || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
+    if (input_dim < 1) return QCN_ERR_UNSUPPORTED;   // the last in-loop GEMM stages the first folded matrix
+    FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 1};
     return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, stream);
 }

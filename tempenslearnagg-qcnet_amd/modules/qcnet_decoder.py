@@ -93,13 +93,17 @@ class QCNetDecoder(nn.Module):
     def _gru_packs(self):
         """traj_emb parameters in the kernels' layouts (k-major transposes), cached per parameter version."""
         gru = self.traj_emb
-        prm = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0, self.traj_emb_h0)
+        out_lin = self.y_emb.to_out[2]
+        prm = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0, self.traj_emb_h0, out_lin.weight, out_lin.bias)
         key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in prm)
         if key != getattr(self, '_gru_key', None):
             C = self.hidden_dim
             with torch.no_grad():
-                wih_t = ops.pack_chain_matrices(list(gru.weight_ih_l0.view(3, C, C)))
-                self._gru_pack = (wih_t, gru.bias_ih_l0.view(3, C).contiguous(), ops.pack_gru_whh(gru.weight_hh_l0, self.traj_emb_h0),
+                # y_emb's last Linear feeds the GRU's input half directly (:255-257): folded into it, one GEMM per row less
+                w_f, b_f = ops.fold_linear(list(gru.weight_ih_l0.view(3, C, C)), list(gru.bias_ih_l0.view(3, C)),
+                                           out_lin.weight, out_lin.bias)
+                wih_t = ops.pack_chain_matrices(w_f)
+                self._gru_pack = (wih_t, b_f, ops.pack_gru_whh(gru.weight_hh_l0, self.traj_emb_h0),
                                   gru.bias_hh_l0.contiguous(), self.traj_emb_h0.reshape(-1).contiguous())
             self._gru_key = key
         return self._gru_pack
@@ -236,7 +240,7 @@ class QCNetDecoder(nn.Module):
         # (reference :255-257); row n * Tf + t of the embedding is step t of mode query n
         wih_t, b_ih, whh, b_hh, h0 = self._gru_packs()
         gi = ops.fourier_linear(loc_propose_pos.detach().reshape(-1, OD).contiguous().float(), OD,
-                                self.y_emb.packed_weights(), wih_t, b_ih)      # y_emb + the GRU's input half, one launch
+                                self.y_emb.packed_weights(), wih_t, b_ih, folded=True)   # y_emb + the GRU's input half, one launch
         m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0)
         m = self._fuse_modes(m, temporal_m)
         m = self._cross_stack('refine', m, *graphs)

@@ -260,8 +260,11 @@ def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor,
     return y
 
 
-def fourier_linear(x: torch.Tensor, input_dim: int, pack: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor]):
-    """qcn_fourier_linear_f32: [W_j FourierEmbedding(x) + b_j] for the n_out <= 3 layers of ``wt`` (pack_chain_matrices)."""
+def fourier_linear(x: torch.Tensor, input_dim: int, pack: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor],
+                   folded: bool = False):
+    """qcn_fourier_linear_f32: [W_j FourierEmbedding(x) + b_j] for the n_out <= 3 layers of ``wt`` (pack_chain_matrices).
+    ``folded``: ``wt`` / ``bias`` already contain the embedding's last Linear (qcn_fourier_folded_linear_f32,
+    :func:`fold_linear`)."""
     dev = pack.device
     _require(x, 'continuous_inputs', torch.float32, dev, (None, input_dim))
     n = x.size(0)
@@ -274,9 +277,19 @@ def fourier_linear(x: torch.Tensor, input_dim: int, pack: torch.Tensor, wt: torc
         _require(bias, 'bias', torch.float32, dev, (n_out, C))
     ys = [torch.empty(n, C, dtype=torch.float32, device=dev) for _ in range(n_out)]
     yp = [_ptr(y) for y in ys] + [None] * (3 - n_out)
-    _lib.check(_lib.lib().qcn_fourier_linear_f32(_ptr(x), int(input_dim), None, 1, _ptr(pack), n, _ptr(wt), _ptr(bias), n_out,
-                                                 yp[0], yp[1], yp[2], _stream(dev)), 'qcn_fourier_linear_f32')
+    fn = _lib.lib().qcn_fourier_folded_linear_f32 if folded else _lib.lib().qcn_fourier_linear_f32
+    _lib.check(fn(_ptr(x), int(input_dim), None, 1, _ptr(pack), n, _ptr(wt), _ptr(bias), n_out,
+                  yp[0], yp[1], yp[2], _stream(dev)), 'qcn_fourier_folded_linear_f32' if folded else 'qcn_fourier_linear_f32')
     return ys
+
+
+def fold_linear(weights, biases, w_inner: torch.Tensor, b_inner: torch.Tensor):
+    """(W_j W_inner, W_j b_inner + b_j) for a stack of Linear layers applied to the output of Linear(w_inner, b_inner)
+    with nothing in between; products in fp64, results fp32."""
+    wi, bi = w_inner.detach().double(), b_inner.detach().double()
+    ws = [(w.detach().double() @ wi).float() for w in weights]
+    bs = [(w.detach().double() @ bi + b.detach().double()).float() for w, b in zip(weights, biases)]
+    return ws, torch.stack(bs).contiguous()
 
 
 def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], wt: torch.Tensor,

@@ -64,6 +64,28 @@ def test_fourier_embedding_large_angles_vs_oracle():
     assert rel_err(got, want) < TOL
 
 
+@pytest.mark.parametrize('n_rows', [1, 77, 3000])
+def test_fourier_folded_linear_equals_two_linear_layers(n_rows):
+    """qcn_fourier_folded_linear_f32 (to_out's Linear folded into the layers behind it, ops.fold_linear) against
+    qcn_fourier_linear_f32 and against the embedding followed by torch Linear layers: rounding only."""
+    from tempenslearnagg_qcnet_amd import ops
+    m = randomize_(FourierEmbedding(input_dim=2, hidden_dim=128, num_freq_bands=64), seed=21).eval().to(DEV)
+    gen = torch.Generator().manual_seed(22)
+    ws = [(torch.randn(128, 128, generator=gen) * 0.1).to(DEV) for _ in range(3)]
+    bs = [(torch.randn(128, generator=gen) * 0.1).to(DEV) for _ in range(3)]
+    x = (torch.randn(n_rows, 2, generator=gen) * 20.0).to(DEV)
+    with torch.no_grad():
+        emb = m(continuous_inputs=x, categorical_embs=None)
+        want = [emb.double() @ w.double().t() + b.double() for w, b in zip(ws, bs)]
+        plain = ops.fourier_linear(x, 2, m.packed_weights(), ops.pack_chain_matrices(ws), torch.stack(bs).contiguous())
+        lin = m.to_out[2]
+        w_f, b_f = ops.fold_linear(ws, bs, lin.weight, lin.bias)
+        folded = ops.fourier_linear(x, 2, m.packed_weights(), ops.pack_chain_matrices(w_f), b_f, folded=True)
+    for j in range(3):
+        assert rel_err(plain[j], want[j]) < 1e-5
+        assert rel_err(folded[j], want[j]) < 1e-5
+
+
 @pytest.mark.parametrize('out_dim', [1, 40, 120])
 def test_mlp_layer_vs_reference_golden(out_dim):
     g = load_golden('ref_layers.npz')
