@@ -219,15 +219,17 @@ __device__ __forceinline__ int rowptr_lower_bound(const int32_t *rowptr, int n_r
 __device__ __forceinline__ void row_chunk(const int32_t *rowptr, int n_rows, int lb, int nb, int lane, int *row_begin, int *row_end)
 {
     using cint = const __attribute__((address_space(4))) int32_t;
-    const int num_edges = *((cint *)(uintptr_t)rowptr + n_rows);
+    const int first_edge = *((cint *)(uintptr_t)rowptr);              // a rowptr that is a slice of a larger CSR starts above 0
+    const int num_edges = *((cint *)(uintptr_t)rowptr + n_rows) - first_edge;
     if (num_edges <= 0) {
         const int per = (n_rows + nb - 1) / nb;
         *row_begin = min(lb * per, n_rows);
         *row_end = min(*row_begin + per, n_rows);
         return;
     }
-    *row_begin = lb == 0 ? 0 : rowptr_lower_bound(rowptr, n_rows, (int)((long long)lb * num_edges / nb), lane);
-    *row_end = lb + 1 >= nb ? n_rows : rowptr_lower_bound(rowptr, n_rows, (int)((long long)(lb + 1) * num_edges / nb), lane);
+    *row_begin = lb == 0 ? 0 : rowptr_lower_bound(rowptr, n_rows, first_edge + (int)((long long)lb * num_edges / nb), lane);
+    *row_end = lb + 1 >= nb ? n_rows
+                            : rowptr_lower_bound(rowptr, n_rows, first_edge + (int)((long long)(lb + 1) * num_edges / nb), lane);
 }
 
 // first tile of the first non-empty row in [row, row_end)

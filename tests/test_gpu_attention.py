@@ -222,6 +222,26 @@ def test_attn_modes_vs_fp64_oracle(layout, K, n_rows, n_src, E, heavy, empty_fro
     _attn_modes_case(layout, K, n_rows, n_src, E, heavy, empty_from)
 
 
+def test_attn_modes_on_a_rowptr_slice():
+    """A rowptr that is a slice of a larger CSR (first entry > 0, col / eid / rhat indexed by absolute edge ids): the
+    edge-balanced row chunks (attention_modes.hip: row_chunk) must still cover exactly the slice's rows."""
+    K, n_rows, n_src, E = 6, 700, 120, 30000
+    base = _graph(n_src, n_rows, E, 47, heavy=200)
+    q, k, v, r = _feat(n_rows * K, 5, 1.5), _feat(n_src, 6, 1.5), _feat(n_src, 7), _feat(E, 8, 2.0)
+    pw = _pos_weights(13)
+    g = CSRGraph.from_edge_index(base.to(DEV), n_src, n_rows).replicate(K, 2)
+    full = _modes(q, k, v, r, g, *pw, rep=K, layout=2)
+    w_kr, w_vr, b_vr, gamma, beta = pw
+    wpack = ops.pack_attn_modes((w_kr * gamma[None]).to(DEV), (w_vr * gamma[None]).to(DEV))
+    bv = (w_vr @ beta + b_vr).to(DEV).contiguous()
+    rs = ops.split_rows(ops.row_normalize(r.to(DEV)))
+    for a, b in ((250, 700), (1, 2), (333, 400)):
+        rowptr = g.rowptr[a:b + 1].contiguous()
+        assert int(rowptr[0]) > 0
+        part = ops.attn_modes(q[a * K:b * K].to(DEV).contiguous(), k.to(DEV), v.to(DEV), rs, rowptr, g.col, g.eid, wpack, bv, K, 2)
+        assert torch.equal(part, full[a * K:b * K])
+
+
 def _attn_modes_case(layout, K, n_rows, n_src, E, heavy, empty_from):
     """qcn_attn_modes_f32 (mode-replicated relations on the matrix cores) against the fp64 oracle on the explicitly
     K-times replicated graph, and against qcn_attn_fused_f32 on the same inputs.  Tolerance 2e-5 relative."""
