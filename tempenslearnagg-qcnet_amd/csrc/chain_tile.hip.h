@@ -291,21 +291,9 @@ __device__ __forceinline__ void load_row(f32x16 (&v)[4], const float *__restrict
 #endif
 }
 
-__device__ __forceinline__ void store_row(const f32x16 (&v)[4], float *__restrict__ dst, int64_t row, int h)
-{
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 x;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) x[j] = v[t][4 * q + j];
-            *reinterpret_cast<f32x4 *>(dst + row * kC + 32 * t + 8 * q + 4 * h) = x;
-        }
-}
-
 // Coalesced row I/O through a per-wave LDS transposition block (4 KiB = the wave's 32 rows x one 32-feature block).
-// load_row / store_row let every lane touch its own 512-B row: one instruction = 32 lines of 32 B.  Here a global
+// load_row (and the per-lane stores it used to be paired with) lets every lane touch its own 512-B row: one instruction =
+// 32 lines of 32 B.  Here a global
 // instruction covers 8 rows x 128 B (full lines: lane L -> row 8 i + (L >> 3), 16-B chunk L & 7) and the lane-owns-row
 // register layout is produced by the LDS: chunk c of row n sits at chunk position c ^ ((n >> 1) & 7) of the row's
 // 128 bytes, which makes both the row-major writes and the (row n, chunks 2 q + h) reads conflict-free.  DS operations
@@ -416,26 +404,39 @@ __device__ __forceinline__ void store_tile2(const f32x16 (&v)[4], float *__restr
     }
 }
 
-// The row as split f16 (the operand format of qcn_attn_modes_f32, see qcn_split_rows_f16): dst row = [hi 128 | lo 128]
-// with hi + lo = v * scale
-__device__ __forceinline__ void store_row_split(const f32x16 (&v)[4], _Float16 *__restrict__ dst, int64_t row, int h, float scale)
+// The row as split f16 (the operand format of qcn_attn_modes_f32, see qcn_split_rows_f16): dst row = [hi 128 | lo 128] with
+// hi + lo = v * scale, through the 2 KiB transposition block: per pass the 16 features of a row are 32 B of hi and 32 B of lo
+// halves (chunks 0, 1 | 2, 3 of the row's 64 bytes, XOR-swizzled as in store_tile2); a global instruction then writes
+// 16 rows x (32 B hi + 32 B lo) instead of 8-byte pieces.
+__device__ __forceinline__ void store_tile2_split(const f32x16 (&v)[4], _Float16 *__restrict__ dst, int64_t row0, int64_t n_rows,
+                                                  f32x4 *xpose, int lane, float scale)
 {
     using half4v = __attribute__((ext_vector_type(4))) _Float16;
+    const int n = lane & 31, h = lane >> 5;
+    half4v *const xh = reinterpret_cast<half4v *>(xpose);          // 8-byte units: row n = units 8 n .. 8 n + 7
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int tp = 0; tp < 8; ++tp) {
+        const int t = tp >> 1, half = tp & 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int qq = 0; qq < 2; ++qq) {
             half4v hi, lo;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float a = v[t][4 * q + j] * scale;
+                const float a = v[t][4 * (2 * half + qq) + j] * scale;
                 hi[j] = (_Float16)a;
                 lo[j] = (_Float16)(a - (float)hi[j]);
             }
-            _Float16 *p = dst + row * (2 * kC) + 32 * t + 8 * q + 4 * h;
-            *reinterpret_cast<half4v *>(p) = hi;
-            *reinterpret_cast<half4v *>(p + kC) = lo;
+            xh[n * 8 + 2 * (qq ^ ((n >> 2) & 3)) + h] = hi;
+            xh[n * 8 + 2 * ((2 + qq) ^ ((n >> 2) & 3)) + h] = lo;
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 16 * i + (lane >> 2), c = lane & 3;
+            const f32x4 x = xpose[r * 4 + (c ^ ((r >> 2) & 3))];
+            if (row0 + r < n_rows)
+                *reinterpret_cast<f32x4 *>(dst + (row0 + r) * (2 * kC) + (c >> 1) * kC + 32 * t + 16 * half + 8 * (c & 1)) = x;
+        }
+    }
 }
 
 // LayerNorm over the 128 features of the lane's row (two-pass mean / variance), optional affine and ReLU

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         skew_after_gemm(skew);
         if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
         if (tail.n_out == 0) {
-            if (normalize_out == 2) { if (valid) store_row_split(acc_o, reinterpret_cast<_Float16 *>(y), row, h, 2048.0f); }
+            if (normalize_out == 2) store_tile2_split(acc_o, reinterpret_cast<_Float16 *>(y), row0, n_rows, xpose, lane, 2048.0f);
             else store_tile2(acc_o, y, row0, n_rows, xpose, lane);
             skew_end(skew);
             return;
