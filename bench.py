@@ -162,7 +162,7 @@ def main() -> None:
     # on a known byte count in the kernel's own access width: scripts/pmc_workload.py, scripts/pmc_summary.py); the
     # counters cannot be read from inside this process, so the committed summary of the same workload is quoted.
     traffic = None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_final_pmc_attention.json')
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_x_pmc_attention.json')
     if args.config == 'cfg3' and batch_size == cfg['batch'] and os.path.exists(pmc_file):
         with open(pmc_file) as fh:
             traffic = json.load(fh)['attn_fused']['traffic_bytes_per_launch']
