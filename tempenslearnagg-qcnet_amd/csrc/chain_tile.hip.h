@@ -487,8 +487,9 @@ __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restri
 
 // rows-per-block choice: WAVES waves x 32 rows.  A block always stages whole matrices, so fewer waves per block only
 // pays when the launch would otherwise leave CUs idle or the last round of blocks mostly empty.  `small_cost` = time of
-// a 4- (or 2-) wave block relative to an 8-wave block's 2.0, measured per kernel on one-round launches (MI355X, split
-// mode: attn_post 55 / 90 us, Fourier in = 3 43 / 57 us, ln_linear x4 33 / 50 us).
+// a 4- (or 2-) wave block relative to an 8-wave block's 2.0, measured per kernel (MI355X, split mode, microseconds per
+// round of blocks: attn_post 50 / 100 — its four-wave blocks keep their rows in registers —, Fourier in = 3 43 / 57,
+// ln_linear x4 33 / 50).
 __host__ inline int pick_waves(int64_t n_rows, bool split, double small_cost = 1.08, int n_cus = 256)
 {
     (void)split;

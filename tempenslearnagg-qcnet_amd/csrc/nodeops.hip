@@ -350,7 +350,7 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
     if (out == agg || out == xn_dst || out == s_proj || out == x_res) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
     const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
-    const int waves = pick_waves(n_rows, split, 1.22);
+    const int waves = pick_waves(n_rows, split, 1.0);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
     void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * kPostMats * 2.0 * kMatFloats, s);
