@@ -30,6 +30,7 @@ extern "C" {
 #define QCN_ERR_UNSUPPORTED (-2)
 #define QCN_ERR_WORKSPACE_TOO_SMALL (-3)
 #define QCN_ERR_LAUNCH_FAILED (-4)
+#define QCN_ERR_TOO_LARGE (-5) /* size beyond the fixed capacity of an allocation-free entry point */
 
 #define QCN_CHANNELS 128
 #define QCN_HEADS 8
@@ -85,6 +86,21 @@ size_t qcn_csr_workspace_bytes(int64_t num_edges, int64_t n_dst);
 int qcn_csr_build(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst,
                   int32_t *rowptr, int32_t *col, int32_t *eid, void *workspace, size_t workspace_bytes,
                   void *stream);
+
+/* qcn_csr_build for callers that cannot allocate — code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  It has no counterpart in the reference (there the indexing happens inside PyG's propagate with
+ * torch's caching allocator behind it).  Same arguments and bit-identical rowptr / col / eid as qcn_csr_build, but the
+ * sort's workspace is a device array that lives inside the library (QCN_CSR_STATIC_SCRATCH_BYTES per GPU the library
+ * runs on, held until the process ends) and the call makes no hipMalloc / hipFree or allocating library call.
+ *   - num_edges <= QCN_CSR_STATIC_MAX_EDGES (qcn_csr_static_max_edges()), else QCN_ERR_TOO_LARGE and nothing is launched;
+ *   - every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two host threads)
+ *     race — serialise them (one stream, or events between them); calls on different GPUs are independent;
+ *   - the device current at the call is the one whose array is used: `stream` must belong to it. */
+#define QCN_CSR_STATIC_MAX_EDGES (1 << 20)
+#define QCN_CSR_STATIC_SCRATCH_BYTES (32 << 20)
+int64_t qcn_csr_static_max_edges(void);
+int qcn_csr_build_static(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst,
+                         int32_t *rowptr, int32_t *col, int32_t *eid, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * A3 — fused gather + segment softmax + weighted scatter-add of AttentionLayer.message / PyG propagate /

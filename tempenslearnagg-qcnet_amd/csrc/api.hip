@@ -86,6 +86,7 @@ extern "C" const char *qcn_status_string(int status)
     case QCN_ERR_UNSUPPORTED: return "unsupported shape or size";
     case QCN_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
     case QCN_ERR_LAUNCH_FAILED: return "HIP launch failed";
+    case QCN_ERR_TOO_LARGE: return "size exceeds the fixed capacity of this allocation-free entry point";
     default: return "unknown status";
     }
 }

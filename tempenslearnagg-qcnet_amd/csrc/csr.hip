@@ -2,6 +2,7 @@
 // Sorting / scanning are rocPRIM device primitives (stable LSD radix sort, single-pass scan): they are the
 // right tool for byte/integer reshuffles; the hand-written kernels around them only convert and search.
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -97,20 +98,11 @@ extern "C" size_t qcn_csr_workspace_bytes(int64_t num_edges, int64_t n_dst)
     return 3 * arr + align256(csr_sort_temp_bytes(num_edges, csr_end_bit(n_dst))) + 256;
 }
 
-extern "C" int qcn_csr_build(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst,
-                             int32_t *rowptr, int32_t *col, int32_t *eid, void *workspace, size_t workspace_bytes,
-                             void *stream)
+// shared body of qcn_csr_build / qcn_csr_build_static: `ws` holds qcn_csr_workspace_bytes(num_edges, n_dst) bytes
+static int csr_build_impl(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst, int32_t *rowptr,
+                          int32_t *col, int32_t *eid, char *ws, hipStream_t s)
 {
-    if (num_edges < 0 || n_dst < 0 || !rowptr) return QCN_ERR_INVALID_ARGUMENT;
-    if (num_edges >= (int64_t)1 << 31 || n_dst >= ((int64_t)1 << 31) - 1) return QCN_ERR_UNSUPPORTED;
-    hipStream_t s = qcn_stream(stream);
-    if (num_edges == 0)
-        return hipMemsetAsync(rowptr, 0, (size_t)(n_dst + 1) * sizeof(int32_t), s) == hipSuccess
-                   ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
-    if (!src || !dst || !col || !eid || !workspace) return QCN_ERR_INVALID_ARGUMENT;
-    if (workspace_bytes < qcn_csr_workspace_bytes(num_edges, n_dst)) return QCN_ERR_WORKSPACE_TOO_SMALL;
     const size_t arr = align256((size_t)num_edges * sizeof(int32_t));
-    char *ws = (char *)workspace;
     int32_t *key_in = (int32_t *)ws;
     int32_t *val_in = (int32_t *)(ws + arr);
     int32_t *key_out = (int32_t *)(ws + 2 * arr);
@@ -128,4 +120,77 @@ extern "C" int qcn_csr_build(const int64_t *src, const int64_t *dst, int64_t num
                        num_edges, n_dst, rowptr, col);
     QCN_CHECK_LAUNCH();
     return QCN_OK;
+}
+
+static int csr_check_args(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst, int32_t *rowptr,
+                          int32_t *col, int32_t *eid)
+{
+    if (num_edges < 0 || n_dst < 0 || !rowptr) return QCN_ERR_INVALID_ARGUMENT;
+    if (num_edges >= (int64_t)1 << 31 || n_dst >= ((int64_t)1 << 31) - 1) return QCN_ERR_UNSUPPORTED;
+    if (num_edges > 0 && (!src || !dst || !col || !eid)) return QCN_ERR_INVALID_ARGUMENT;
+    return QCN_OK;
+}
+
+extern "C" int qcn_csr_build(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst,
+                             int32_t *rowptr, int32_t *col, int32_t *eid, void *workspace, size_t workspace_bytes,
+                             void *stream)
+{
+    const int st = csr_check_args(src, dst, num_edges, n_dst, rowptr, col, eid);
+    if (st != QCN_OK) return st;
+    hipStream_t s = qcn_stream(stream);
+    if (num_edges == 0)
+        return hipMemsetAsync(rowptr, 0, (size_t)(n_dst + 1) * sizeof(int32_t), s) == hipSuccess
+                   ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
+    if (!workspace) return QCN_ERR_INVALID_ARGUMENT;
+    if (workspace_bytes < qcn_csr_workspace_bytes(num_edges, n_dst)) return QCN_ERR_WORKSPACE_TOO_SMALL;
+    return csr_build_impl(src, dst, num_edges, n_dst, rowptr, col, eid, (char *)workspace, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// qcn_csr_build_static — the same CSR build for callers that cannot allocate (HIP graph capture, serving loops):
+// the sort's workspace (keys, edge ids, sorted keys, radix-sort temporaries) is this file-scope device array instead
+// of a caller buffer.  Every GPU the library runs on holds its own copy until the process ends; the array's name is a
+// host-side stand-in, so its per-device address is looked up once per device (hipGetSymbolAddress with that device
+// current) and only that pointer is ever handed to kernels.
+// ------------------------------------------------------------------------------------------------
+static __device__ __align__(256) unsigned char scratch[QCN_CSR_STATIC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+unsigned char *g_scratch_ptr[kMaxDevices] = {};
+}  // namespace
+
+// device pointer of `scratch` on the current device (nullptr on failure)
+static unsigned char *csr_static_scratch()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return nullptr;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || p == nullptr) return nullptr;
+        g_scratch_ptr[dev] = static_cast<unsigned char *>(p);
+    }
+    return g_scratch_ptr[dev];
+}
+
+extern "C" int64_t qcn_csr_static_max_edges(void) { return QCN_CSR_STATIC_MAX_EDGES; }
+
+extern "C" int qcn_csr_build_static(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst,
+                                    int32_t *rowptr, int32_t *col, int32_t *eid, void *stream)
+{
+    const int st = csr_check_args(src, dst, num_edges, n_dst, rowptr, col, eid);
+    if (st != QCN_OK) return st;
+    if (num_edges > QCN_CSR_STATIC_MAX_EDGES) return QCN_ERR_TOO_LARGE;
+    hipStream_t s = qcn_stream(stream);
+    if (num_edges == 0)
+        return hipMemsetAsync(rowptr, 0, (size_t)(n_dst + 1) * sizeof(int32_t), s) == hipSuccess
+                   ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
+    if (qcn_csr_workspace_bytes(num_edges, n_dst) > (size_t)QCN_CSR_STATIC_SCRATCH_BYTES) return QCN_ERR_TOO_LARGE;
+    unsigned char *ws = csr_static_scratch();
+    if (ws == nullptr) return QCN_ERR_LAUNCH_FAILED;
+    // nothing in the workspace has to start at zero: the prepare kernel writes every key / id slot the sort reads and
+    // rocPRIM initialises its own histograms inside `temp`; whatever the previous call left behind is overwritten
+    return csr_build_impl(src, dst, num_edges, n_dst, rowptr, col, eid, (char *)ws, s);
 }

@@ -109,6 +109,29 @@ def csr_build(edge_index: torch.Tensor, n_dst: int) -> Tuple[torch.Tensor, torch
     return rowptr, col, eid
 
 
+def csr_static_max_edges() -> int:
+    return int(_lib.lib().qcn_csr_static_max_edges())
+
+
+def csr_build_static(edge_index: torch.Tensor, n_dst: int, rowptr: torch.Tensor, col: torch.Tensor,
+                     eid: torch.Tensor) -> None:
+    """qcn_csr_build_static: csr_build into CALLER-provided outputs with the sort workspace inside the library — the call
+    allocates nothing (for code under HIP graph capture / serving loops).  At most csr_static_max_edges() edges; calls
+    that overlap on one GPU race (they share the library's per-GPU scratch array)."""
+    dev = edge_index.device
+    _require(edge_index, 'edge_index', torch.int64, dev, (2, None))
+    num_edges = edge_index.size(1)
+    _require(rowptr, 'rowptr', torch.int32, dev, (n_dst + 1,))
+    _require(col, 'col', torch.int32, dev, (num_edges,))
+    _require(eid, 'eid', torch.int32, dev, (num_edges,))
+    if torch.cuda.current_device() != dev.index:
+        raise ValueError('csr_build_static uses the scratch array of the CURRENT device; make %s current' % dev)
+    src = ctypes.c_void_p(edge_index.data_ptr())
+    dst = ctypes.c_void_p(edge_index.data_ptr() + 8 * num_edges)
+    _lib.check(_lib.lib().qcn_csr_build_static(src, dst, num_edges, n_dst, _ptr(rowptr), _ptr(col), _ptr(eid),
+                                               _stream(dev)), 'qcn_csr_build_static')
+
+
 # ------------------------------------------------------------------------------------------------
 # attention propagate
 # ------------------------------------------------------------------------------------------------
