@@ -161,18 +161,34 @@ int qcn_attn_modes_f32(const float *q, const float *k, const float *v, const voi
                        const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
                        int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream);
 
-/* Arithmetic of the three MFMA chain kernels below (qcn_fourier_embed_f32, qcn_ln_linear_f32, qcn_attn_post_f32).
+/* The same relation with bf16 positional projections (QCN_MATMUL_BF16 below; BASELINE.json configs[3]): the operands of the two
+ * per-edge products W_kr LN_r(r_e), W_vr LN_r(r_e) are rounded to bf16 (round to nearest even), one v_mfma_f32_16x16x32_bf16
+ * per product, fp32 accumulation; k[j] / v[j], the logits, the softmax and the weighted sums stay fp32.
+ *   rhat_bf16 [E_base rows, 128] bf16 (a normalising qcn_fourier_embed_f32 with normalize_out = 3, or any RNE cast of rhat);
+ *   wpack: qcn_attn_modes_bf16_pack_bytes() bytes = [head 8][wk | wv][k-step 4][lane 64][8 bf16], frag as above without
+ *   scaling (host: ops.pack_attn_modes(mode=QCN_MATMUL_BF16)).  Everything else as qcn_attn_modes_f32. */
+size_t qcn_attn_modes_bf16_pack_bytes(void);
+int qcn_attn_modes_bf16(const float *q, const float *k, const float *v, const void *rhat_bf16,
+                        const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                        const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                        int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream);
+
+/* Arithmetic of the MFMA chain kernels below (qcn_fourier_*_f32, qcn_ln_linear_f32, qcn_attn_post_f32, qcn_mlp_heads_f32,
+ * qcn_gru_f32): their `matmul_mode` argument.  The library keeps no mode of its own (no global mutable state: every call
+ * names its arithmetic, calls are re-entrant); weight packs are mode specific — pass the pack made for the same mode.
  *   QCN_MATMUL_EXACT_F32: v_mfma_f32_32x32x2_f32, exact fp32 fma chains.
- *   QCN_MATMUL_SPLIT_F16 (default): every fp32 operand carried as hi + lo of two f16 numbers (22 significant bits)
- *     after an exact power-of-two scaling of each activation row / weight matrix to [2^14, 2^15); products
- *     hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16, fp32 accumulation.  Results agree with the exact mode to a few
- *     fp32 ulps (operand error <= max(2^-22 |x|, 2^-29 max|x|)); finite for |x| < 2^64.
- * The mode is process-global, read at launch; weight packs are mode specific (pass the pack made for the mode in force:
- * ops.pack_chain_matrix consults qcn_get_matmul_mode).  No counterpart in the reference (its matmuls are torch fp32). */
+ *   QCN_MATMUL_SPLIT_F16: every fp32 operand carried as hi + lo of two f16 numbers (22 significant bits) after an exact
+ *     power-of-two scaling of each activation row / weight matrix to [2^14, 2^15); products hi*hi + hi*lo + lo*hi on
+ *     v_mfma_f32_32x32x16_f16, fp32 accumulation.  Results agree with the exact mode to a few fp32 ulps (operand error
+ *     <= max(2^-22 |x|, 2^-29 max|x|)); finite for |x| < 2^64.  The fp32-equivalent default of the Python layer.
+ *   QCN_MATMUL_BF16: every matrix operand (weights and activations) rounded to bf16, round-to-nearest-even, one
+ *     v_mfma_f32_32x32x16_bf16 per product, fp32 accumulation; biases, rank-1 terms, LayerNorm, activations and residuals
+ *     stay fp32 — BASELINE.json configs[3] ("bf16 projections"; the reference's counterpart would be autocast around its
+ *     nn.Linear layers, layers/attention_layer.py:40-55, layers/fourier_embedding.py:34-46).  qcn_gru_f32 has no bf16
+ *     form: the 60-step recurrence stays in the split mode (the GRU's INPUT projections follow the mode). */
 #define QCN_MATMUL_EXACT_F32 0
 #define QCN_MATMUL_SPLIT_F16 1
-int qcn_set_matmul_mode(int mode);
-int qcn_get_matmul_mode(void);
+#define QCN_MATMUL_BF16 2
 
 /* Chain-packed 128x128 matrix — the weight layout of the three MFMA chain kernels (csrc/chain_tile.hip.h): 16384 floats
  * plus a {scale, 1 / scale} pair that travels in the scale table of the pack.  For W = nn.Linear(128,128).weight
@@ -183,6 +199,8 @@ int qcn_get_matmul_mode(void);
  *   split: W' = W * 2^(15 - e), 2^(e-1) <= max|W| < 2^e; hi = f16(W'), lo = f16(W' - hi);
  *          P[j][t][p][lane][i] = plane_p(W'[32 t + (lane & 31)][kin(8 j + i, lane >> 5)]),  j = 0..7, p = 0 (hi), 1 (lo),
  *          i = 0..7 (f16, 32768 of them); scale pair {2^(15 - e), 2^(e - 15)}.
+ *   bf16:  P[j][t][lane][i] = bf16(W[32 t + (lane & 31)][kin(8 j + i, lane >> 5)]) (16384 bf16 = the first 8192 floats of
+ *          the 16384-float slot, the rest is ignored); scale pair {1, 1}.
  * The first layer of a FourierEmbedding MLP uses kin(s, h) = 32 h + s for s < 32 (cosines) and 64 + 32 h + (s - 32)
  * otherwise (sines).  Host packer: ops.pack_chain_matrix. */
 
@@ -192,7 +210,8 @@ int qcn_get_matmul_mode(void);
  *   repeats one type embedding per agent over T steps: extra_div = T); y [n_rows, 128].
  *   normalize_out != 0 additionally applies (y - mean) / sqrt(var + 1e-5) per row, the layer-independent half of the
  *   consuming AttentionLayers' attn_prenorm_r (layers/attention_layer.py:82); normalize_out == 2 writes that result
- *   as split-f16 rows instead (y = [n_rows, 256] f16, scale 2^11: the rhat_split operand of qcn_attn_modes_f32).
+ *   as split-f16 rows instead (y = [n_rows, 256] f16, scale 2^11: the rhat_split operand of qcn_attn_modes_f32),
+ *   normalize_out == 3 as bf16 rows (y = [n_rows, 128] bf16, round to nearest even: the operand of qcn_attn_modes_bf16).
  *   pack: qcn_fourier_pack_floats(input_dim) floats: the 2 input_dim + 1 chain-packed matrices
  *     [mlps.0.0.weight[:, :128] (cos | sin order above), mlps.0.3.weight, mlps.1.0.weight[:, :128], ..., to_out.2.weight]
  *   then per input dim i
@@ -202,14 +221,14 @@ int qcn_get_matmul_mode(void);
  *   hidden_dim = 128, num_freq_bands = 64 only. */
 size_t qcn_fourier_pack_floats(int input_dim);
 int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
-                          const float *pack, int64_t n_rows, int normalize_out, float *y, void *stream);
+                          const float *pack, int64_t n_rows, int normalize_out, float *y, int matmul_mode, void *stream);
 
 /* A4 followed by up to three Linear(128,128) layers on the embedding before it leaves the registers:
  * y_j = W_j FourierEmbedding(x) + b_j, j < n_out <= 3 (the decoder's trajectory re-encoding, modules/qcnet_decoder.py:255-257:
  * y_emb followed by the GRU's input half W_i* y + b_i*).  wt / bias as for qcn_ln_linear_f32; the embedding is not stored. */
 int qcn_fourier_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
                            const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
-                           float *y0, float *y1, float *y2, void *stream);
+                           float *y0, float *y1, float *y2, int matmul_mode, void *stream);
 
 /* The same chain with the embedding's last Linear (to_out.2, layers/fourier_embedding.py:42-46,67) folded into the layers
  * that follow it: there is no non-linearity between to_out.2 and W_j, so the caller passes W'_j = W_j W_out and
@@ -218,7 +237,7 @@ int qcn_fourier_linear_f32(const float *x, int input_dim, const float *extra, in
  * modules/qcnet_decoder.py:255-257); results differ from qcn_fourier_linear_f32 by fp32 rounding only. */
 int qcn_fourier_folded_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
                                   const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
-                                  float *y0, float *y1, float *y2, void *stream);
+                                  float *y0, float *y1, float *y2, int matmul_mode, void *stream);
 
 /* A2 node side (K5/K6 of SURVEY.md §2b fused) — xn = LayerNorm(x) (skipped when ln_weight == NULL);
  * y_j = W_j xn + b_j for j < n_out <= 4 (the to_q / to_k / to_v / to_s projections of one AttentionLayer call,
@@ -226,7 +245,7 @@ int qcn_fourier_folded_linear_f32(const float *x, int input_dim, const float *ex
  * (16384 floats each) followed by their n_out {scale, 1 / scale} pairs; bias: [n_out,128] or NULL; xn_out may be NULL. */
 int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
                       const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
-                      float *y3, float *xn_out, void *stream);
+                      float *y3, float *xn_out, int matmul_mode, void *stream);
 
 /* A2 node side, after the propagate — gate/update, to_out, post-norm residual and the whole feed-forward block
  * (layers/attention_layer.py:83-84,106-108,119,121-122):
@@ -242,7 +261,7 @@ int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, co
  * x1 between the two residuals). */
 size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
-                      const float *pack, int64_t n_rows, float *out, void *stream);
+                      const float *pack, int64_t n_rows, float *out, int matmul_mode, void *stream);
 
 /* G0 / K7 — relative geometry of an edge list (utils/geometry.py:19-23 angle_between_2d_vectors, :47-51 wrap_angle, and
  * their call sites modules/qcnet_map_encoder.py:121-128, qcnet_agent_encoder.py:133-139,161-176, qcnet_decoder.py:161-206):
@@ -261,7 +280,7 @@ int qcn_rel_geometry_f32(const float *pos_src, int pos_stride_src, const float *
  * the scale table (32 floats). */
 size_t qcn_mlp_heads_pack_floats(int n_heads);
 int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pack, int n_heads, const int *out_dims,
-                      float *y0, float *y1, float *y2, void *stream);
+                      float *y0, float *y1, float *y2, int matmul_mode, void *stream);
 
 /* K10 — recurrent half of the decoder's nn.GRU(128,128) trajectory embedder (modules/qcnet_decoder.py:86-88,257),
  * final hidden state only.  gi_r / gi_z / gi_n [n_seq * n_steps, 128]: the input half W_i* x_t + b_i* for row
@@ -275,7 +294,8 @@ int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pack, int n_h
  *          Host packer: ops.pack_gru_whh. */
 size_t qcn_gru_pack_floats(void);
 int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh,
-                const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, void *stream);
+                const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, int matmul_mode,
+                void *stream);
 
 /* K6 — y = (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine; the layer-independent half
  * of attn_prenorm_r, layers/attention_layer.py:63,82). */
@@ -357,16 +377,6 @@ int qcn_to_world_frame_f32(const float *traj, int traj_dim, const float *positio
 int qcn_nms_select_f32(const float *traj, const float *conf, const float *gt, int64_t n_agents, int n_cand_total,
                        int n_steps, int n_windows, int cand_per_window, int n_select, float radius, float miss_threshold,
                        int *selected, float *score, void *stream);
-
-/* Optional per-launch timing of the hand-written kernels with hipEvents on the launch stream (bench.py roofline
- * leg).  qcn_prof_enable(mask) records the kernel families whose bit (1 << kind) is set
- * (negative: all, 0: off; each recorded launch costs two event records on the stream, so time only what is reported); qcn_prof_collect(kind, ...) synchronises the recorded events of one
- * kernel family (0 = qcn_attn_fwd_f32, 1 = qcn_attn_fused_f32, ...; -1 = all) and returns the number of launches,
- * the summed kernel milliseconds and the summed algorithmic units (bytes for the HBM-bound kernels:
- * SURVEY.md §8(d) 2064*E + 1024*n_dst materialised, 1552*E + 1024*n_dst fused, 1040*E + 1024*n_dst without
- * positional terms), then drops those records. */
-int qcn_prof_enable(int on);
-int qcn_prof_collect(int kind, int64_t *launches_host, double *millis_host, double *alg_units_host);
 
 #ifdef __cplusplus
 }

@@ -193,7 +193,38 @@ def segment_softmax(src: Tensor, index: Tensor, num_nodes: Optional[int] = None)
 # --------------------------------------------------------------------------------------------
 # layers
 # --------------------------------------------------------------------------------------------
+# bf16-operand mode (BASELINE.json configs[3] "bf16 projections"; no counterpart in the reference's files, whose Linear
+# layers are plain fp32 — its counterpart would be autocast).  Inside ``with bf16_operands():`` every nn.Linear of the path
+# multiplies operands rounded to bf16 (round to nearest even, as torch's .bfloat16()) and accumulates in fp32 — the
+# arithmetic contract of the product's QCN_MATMUL_BF16 mode (include/qcnet_hip.h), restated here so that the HIP path can be
+# checked against the SAME operands:
+#   * biases, the x column of a FourierEmbedding's first layer (a rank-1 fp32 term), LayerNorm, activations, residuals and
+#     the GRU recurrence stay fp32;
+#   * the positional projections to_k_r / to_v_r of the decoder's mode relations (t2m / pl2m / a2m) take the row-normalised
+#     r and the weight with the attn_prenorm_r scale folded in as their bf16 operands (W * gamma), the shift as an fp32 bias
+#     (W beta + b); those of the encoder relations stay fp32 (the product folds them onto the queries in fp32).
+_BF16_OPERANDS = False
+
+
+class bf16_operands:
+    def __enter__(self):
+        global _BF16_OPERANDS
+        self._prev, _BF16_OPERANDS = _BF16_OPERANDS, True
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16_OPERANDS
+        _BF16_OPERANDS = self._prev
+        return False
+
+
+def _rb(x: Tensor) -> Tensor:
+    return x.bfloat16().float()
+
+
 def _linear(sd: Mapping[str, Tensor], p: str, x: Tensor) -> Tensor:
+    if _BF16_OPERANDS:
+        return F.linear(_rb(x), _rb(sd[p + 'weight']), sd.get(p + 'bias'))
     return F.linear(x, sd[p + 'weight'], sd.get(p + 'bias'))
 
 
@@ -214,7 +245,12 @@ def fourier_embedding(sd: Mapping[str, Tensor], p: str, continuous_inputs: Optio
         feat = torch.cat([ang.cos(), ang.sin(), continuous_inputs.unsqueeze(-1)], dim=-1)  # :60
         x = None
         for i in range(freqs.size(0)):                                   # :62-64
-            h = _linear(sd, '%smlps.%d.0.' % (p, i), feat[:, i])
+            if _BF16_OPERANDS:   # the 2F Fourier features are matrix operands, the x column a rank-1 fp32 term
+                w, nf = sd['%smlps.%d.0.weight' % (p, i)], feat.size(-1) - 1
+                h = (F.linear(_rb(feat[:, i, :nf]), _rb(w[:, :nf]), sd['%smlps.%d.0.bias' % (p, i)])
+                     + feat[:, i, nf:] * w[:, nf])
+            else:
+                h = _linear(sd, '%smlps.%d.0.' % (p, i), feat[:, i])
             h = F.relu(_layer_norm(sd, '%smlps.%d.1.' % (p, i), h))
             h = _linear(sd, '%smlps.%d.3.' % (p, i), h)
             x = h if x is None else x + h
@@ -244,7 +280,11 @@ def attention_layer(sd: Mapping[str, Tensor], p: str,
         x_src = _layer_norm(sd, p + 'attn_prenorm_x_src.', x[0])
         x_dst = _layer_norm(sd, p + 'attn_prenorm_x_dst.', x[1])
         x = x[1]
+    mode_relation = any(tag in p for tag in ('t2m_', 'pl2m_', 'a2m_'))
+    r_hat = None
     if has_pos_emb and r is not None:                                    # :81-82
+        if _BF16_OPERANDS and mode_relation:
+            r_hat = F.layer_norm(r, (r.size(-1),), None, None, 1e-5)
         r = _layer_norm(sd, p + 'attn_prenorm_r.', r)
     # _attn_block :110-119
     H, D = num_heads, head_dim
@@ -253,9 +293,18 @@ def attention_layer(sd: Mapping[str, Tensor], p: str,
     v = _linear(sd, p + 'to_v.', x_src).view(-1, H, D)
     src, dst = edge_index[0], edge_index[1]
     q_i, k_j, v_j = q.index_select(0, dst), k.index_select(0, src), v.index_select(0, src)   # PyG __collect__
-    if has_pos_emb and r is not None:                                    # message :94-96
-        k_j = k_j + _linear(sd, p + 'to_k_r.', r).view(-1, H, D)
-        v_j = v_j + _linear(sd, p + 'to_v_r.', r).view(-1, H, D)
+    if has_pos_emb and r is not None and r_hat is not None:              # bf16 mode, decoder mode relations (see above)
+        gamma, beta = sd[p + 'attn_prenorm_r.weight'], sd[p + 'attn_prenorm_r.bias']
+        wk, wv = sd[p + 'to_k_r.weight'] * gamma, sd[p + 'to_v_r.weight'] * gamma
+        bv = sd[p + 'to_v_r.weight'] @ beta + sd[p + 'to_v_r.bias']
+        k_j = k_j + (F.linear(_rb(r_hat), _rb(wk)) + sd[p + 'to_k_r.weight'] @ beta).view(-1, H, D)
+        v_j = v_j + F.linear(_rb(r_hat), _rb(wv), bv).view(-1, H, D)
+    elif has_pos_emb and r is not None:                                  # message :94-96
+        fp32 = _BF16_OPERANDS                                            # bf16 mode: encoder relations stay fp32
+        lin = (lambda q_, x_: F.linear(x_, sd[q_ + 'weight'], sd.get(q_ + 'bias'))) if fp32 else \
+            (lambda q_, x_: _linear(sd, q_, x_))
+        k_j = k_j + lin(p + 'to_k_r.', r).view(-1, H, D)
+        v_j = v_j + lin(p + 'to_v_r.', r).view(-1, H, D)
     sim = (q_i * k_j).sum(dim=-1) * (D ** -0.5)                          # :97
     attn = segment_softmax(sim, dst)                                     # :98
     msg = v_j * attn.unsqueeze(-1)                                       # :101
@@ -274,7 +323,7 @@ def gru_last_hidden(sd: Mapping[str, Tensor], p: str, seq: Tensor, h0: Tensor) -
     w_ih, w_hh = sd[p + 'weight_ih_l0'], sd[p + 'weight_hh_l0']
     b_ih, b_hh = sd[p + 'bias_ih_l0'], sd[p + 'bias_hh_l0']
     h = h0
-    gi_all = F.linear(seq, w_ih, b_ih)
+    gi_all = F.linear(_rb(seq), _rb(w_ih), b_ih) if _BF16_OPERANDS else F.linear(seq, w_ih, b_ih)   # recurrence: fp32
     for t in range(seq.size(0)):
         gi = gi_all[t]
         gh = F.linear(h, w_hh, b_hh)

@@ -56,33 +56,33 @@ def _declare(lib) -> None:
     lib.qcn_fourier_pack_floats.restype = c_size_t
     lib.qcn_fourier_pack_floats.argtypes = [c_int]
     lib.qcn_fourier_embed_f32.restype = c_int
-    lib.qcn_fourier_embed_f32.argtypes = [P, c_int, P, c_int64, P, c_int64, c_int, P, P]
+    lib.qcn_fourier_embed_f32.argtypes = [P, c_int, P, c_int64, P, c_int64, c_int, P, c_int, P]
     lib.qcn_ln_linear_f32.restype = c_int
-    lib.qcn_ln_linear_f32.argtypes = [P, c_int64, P, P, P, P, c_int, P, P, P, P, P, P]
+    lib.qcn_ln_linear_f32.argtypes = [P, c_int64, P, P, P, P, c_int, P, P, P, P, P, c_int, P]
     lib.qcn_attn_post_pack_floats.restype = c_size_t
     lib.qcn_attn_post_pack_floats.argtypes = []
     lib.qcn_attn_post_f32.restype = c_int
-    lib.qcn_attn_post_f32.argtypes = [P, P, P, P, P, c_int64, P, P]
+    lib.qcn_attn_post_f32.argtypes = [P, P, P, P, P, c_int64, P, c_int, P]
     lib.qcn_gru_f32.restype = c_int
-    lib.qcn_gru_f32.argtypes = [P, P, P, P, P, P, c_int64, c_int, P, P]
+    lib.qcn_gru_f32.argtypes = [P, P, P, P, P, P, c_int64, c_int, P, c_int, P]
     lib.qcn_row_normalize_f32.restype = c_int
     lib.qcn_row_normalize_f32.argtypes = [P, P, c_int64, c_float, P]
     lib.qcn_mlp_heads_pack_floats.restype = c_size_t
     lib.qcn_mlp_heads_pack_floats.argtypes = [c_int]
     lib.qcn_mlp_heads_f32.restype = c_int
-    lib.qcn_mlp_heads_f32.argtypes = [P, c_int64, P, c_int, POINTER(c_int), P, P, P, P]
+    lib.qcn_mlp_heads_f32.argtypes = [P, c_int64, P, c_int, POINTER(c_int), P, P, P, c_int, P]
     lib.qcn_rel_geometry_f32.restype = c_int
     lib.qcn_rel_geometry_f32.argtypes = [P, c_int, P, c_int, P, P, P, P, P, c_int64, P, P]
     lib.qcn_fourier_linear_f32.restype = c_int
-    lib.qcn_fourier_linear_f32.argtypes = [P, c_int, P, c_int64, P, c_int64, P, P, c_int, P, P, P, P]
+    lib.qcn_fourier_linear_f32.argtypes = [P, c_int, P, c_int64, P, c_int64, P, P, c_int, P, P, P, c_int, P]
     lib.qcn_fourier_folded_linear_f32.restype = c_int
-    lib.qcn_fourier_folded_linear_f32.argtypes = [P, c_int, P, c_int64, P, c_int64, P, P, c_int, P, P, P, P]
+    lib.qcn_fourier_folded_linear_f32.argtypes = [P, c_int, P, c_int64, P, c_int64, P, P, c_int, P, P, P, c_int, P]
     lib.qcn_gru_pack_floats.restype = c_size_t
     lib.qcn_gru_pack_floats.argtypes = []
-    lib.qcn_set_matmul_mode.restype = c_int
-    lib.qcn_set_matmul_mode.argtypes = [c_int]
-    lib.qcn_get_matmul_mode.restype = c_int
-    lib.qcn_get_matmul_mode.argtypes = []
+    lib.qcn_attn_modes_bf16_pack_bytes.restype = c_size_t
+    lib.qcn_attn_modes_bf16_pack_bytes.argtypes = []
+    lib.qcn_attn_modes_bf16.restype = c_int
+    lib.qcn_attn_modes_bf16.argtypes = list(lib.qcn_attn_modes_f32.argtypes)
     lib.qcn_motion_metrics_f32.restype = c_int
     lib.qcn_motion_metrics_f32.argtypes = [P, c_int, P, P, c_int, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_float, P, P]
@@ -102,16 +102,12 @@ def _declare(lib) -> None:
     lib.qcn_coalesce_fill.argtypes = [P, P, c_int64, c_int64, P, P, P, P]
     lib.qcn_nms_select_f32.restype = c_int
     lib.qcn_nms_select_f32.argtypes = [P, P, P, c_int64, c_int, c_int, c_int, c_int, c_int, c_float, c_float, P, P, P]
-    lib.qcn_prof_enable.restype = c_int
-    lib.qcn_prof_enable.argtypes = [c_int]
-    lib.qcn_prof_collect.restype = c_int
-    lib.qcn_prof_collect.argtypes = [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]
 
 
 EXPORTED_SYMBOLS = (
     'qcn_version', 'qcn_status_string', 'qcn_radius_count', 'qcn_radius_fill', 'qcn_scan_workspace_bytes',
     'qcn_exclusive_scan_i32', 'qcn_csr_workspace_bytes', 'qcn_csr_build', 'qcn_attn_fwd_f32',
-    'qcn_attn_fused_f32', 'qcn_row_normalize_f32', 'qcn_fourier_pack_floats', 'qcn_fourier_embed_f32', 'qcn_ln_linear_f32', 'qcn_attn_post_pack_floats', 'qcn_attn_post_f32', 'qcn_gru_f32', 'qcn_prof_enable', 'qcn_prof_collect', 'qcn_set_matmul_mode', 'qcn_get_matmul_mode', 'qcn_gru_pack_floats', 'qcn_fourier_linear_f32', 'qcn_fourier_folded_linear_f32', 'qcn_rel_geometry_f32', 'qcn_mlp_heads_pack_floats', 'qcn_mlp_heads_f32',
+    'qcn_attn_fused_f32', 'qcn_row_normalize_f32', 'qcn_fourier_pack_floats', 'qcn_fourier_embed_f32', 'qcn_ln_linear_f32', 'qcn_attn_post_pack_floats', 'qcn_attn_post_f32', 'qcn_gru_f32', 'qcn_attn_modes_bf16_pack_bytes', 'qcn_attn_modes_bf16', 'qcn_gru_pack_floats', 'qcn_fourier_linear_f32', 'qcn_fourier_folded_linear_f32', 'qcn_rel_geometry_f32', 'qcn_mlp_heads_pack_floats', 'qcn_mlp_heads_f32',
     'qcn_split_rows_f16', 'qcn_attn_modes_pack_bytes', 'qcn_attn_modes_f32',
     'qcn_motion_metrics_f32', 'qcn_to_agent_frame_f32', 'qcn_to_world_frame_f32', 'qcn_nms_select_f32',
     'qcn_csr_static_max_edges', 'qcn_csr_build_static',

@@ -111,7 +111,6 @@ extern "C" int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, 
     const unsigned grid = (unsigned)((n_dst + 3) / 4);
     const bool has_r = kr != nullptr && num_edges > 0;
 
-    void *token = qcn_prof_begin(QCN_PROF_ATTN, (has_r ? 2064.0 : 1040.0) * (double)num_edges + 1024.0 * (double)n_dst, s);
     if (has_r) {
         if (eid)
             hipLaunchKernelGGL((attn_fwd_kernel<true, true>), dim3(grid), dim3(256), 0, s, q, k, v, kr, vr, rowptr, col,
@@ -124,6 +123,5 @@ extern "C" int qcn_attn_fwd_f32(const float *q, const float *k, const float *v, 
                            eid, n_dst, out);
     }
     const bool ok = hipGetLastError() == hipSuccess;
-    qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }

@@ -395,12 +395,10 @@ extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v
     int64_t grid = (n_dst / R + waves - 1) / waves;
     if (grid > 256) grid = 256;
     hipStream_t s = qcn_stream(stream);
-    void *token = qcn_prof_begin(QCN_PROF_ATTN_FUSED, 1552.0 * (double)num_edges * (double)rep + 1024.0 * (double)n_dst, s);
 #define QCN_LAUNCH(E, RR) hipLaunchKernelGGL((attn_fused_kernel<E, RR>), dim3((unsigned)grid), dim3(64 * (RR == 1 ? kWaves : (RR <= 3 ? kWaves / 2 : kWaves / 4))), 0, s, args)
     if (eid) { if (R == 6) QCN_LAUNCH(true, 6); else if (R == 3) QCN_LAUNCH(true, 3); else if (R == 2) QCN_LAUNCH(true, 2); else QCN_LAUNCH(true, 1); }
     else     { if (R == 6) QCN_LAUNCH(false, 6); else if (R == 3) QCN_LAUNCH(false, 3); else if (R == 2) QCN_LAUNCH(false, 2); else QCN_LAUNCH(false, 1); }
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
-    qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }

@@ -38,6 +38,7 @@ constexpr float kLog2e = 1.4426950408889634f;
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v)
@@ -54,7 +55,7 @@ __device__ __forceinline__ void wave_lds_fence()
 
 struct ModesArgs {
     const float *q, *k, *v;
-    const _Float16 *rs;            // [rows, 256] split rhat
+    const void *rs;                // [rows, 256] split-f16 rhat (512 B per row) or [rows, 128] bf16 rhat (256 B per row)
     const int32_t *rowptr, *col, *eid;
     const half8 *wfrag;            // [head][k|v][ks][hi|lo][lane] fragments, then {usc_k, usc_v}
     const float *bv;
@@ -166,17 +167,32 @@ struct Slot {
     unsigned char r[kTile * kRowBytes], k[kTile * kRowBytes], v[kTile * kRowBytes];
 };
 
+template <bool BF16>
 __device__ __forceinline__ void issue_tile_dma(const ModesArgs &a, const TileIdx &x, Slot *slot, int wave, int lane)
 {
     const int e = 2 * wave + (lane >> 5), pc = lane & 31;
-    const uint32_t cr = (uint32_t)(((pc & 15) ^ e) | (pc & 16));     // rhat: logical chunk (hi half 0..15, lo half 16..31)
     const uint32_t ck = (uint32_t)(pc ^ e);                          // k / v: logical chunk
-    const char *sr = reinterpret_cast<const char *>(a.rs) + ((uint32_t)x.rid * 512u + cr * 16u);
     const char *sk = reinterpret_cast<const char *>(a.k) + ((uint32_t)x.src * 512u + ck * 16u);
     const char *sv = reinterpret_cast<const char *>(a.v) + ((uint32_t)x.src * 512u + ck * 16u);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sr,
-                                     (__attribute__((address_space(3))) void *)(slot->r + wave * 1024), 16, 0, 0);
+    if constexpr (BF16) {
+        // a bf16 rhat row is 16 chunks: lanes 0..31 copy rows 2 w (lanes 0..15) and 2 w + 1 (lanes 16..31), 512 B per wave,
+        // chunk c of row e at c ^ e; the upper half of the wave sits the instruction out (every wave still issues it once,
+        // so the vmcnt bookkeeping of the pipeline is the same as in the f16 form)
+        const int rid0 = __builtin_amdgcn_readlane(x.rid, 0), rid1 = __builtin_amdgcn_readlane(x.rid, 32);
+        const int er = 2 * wave + ((lane >> 4) & 1);
+        const uint32_t cr = (uint32_t)((lane & 15) ^ er);
+        const char *sr = reinterpret_cast<const char *>(a.rs) + ((uint32_t)((lane & 16) ? rid1 : rid0) * 256u + cr * 16u);
+        __builtin_amdgcn_sched_barrier(0);
+        if (lane < 32)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sr,
+                                             (__attribute__((address_space(3))) void *)(slot->r + wave * 512), 16, 0, 0);
+    } else {
+        const uint32_t cr = (uint32_t)(((pc & 15) ^ e) | (pc & 16));     // rhat: logical chunk (hi half 0..15, lo half 16..31)
+        const char *sr = reinterpret_cast<const char *>(a.rs) + ((uint32_t)x.rid * 512u + cr * 16u);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sr,
+                                         (__attribute__((address_space(3))) void *)(slot->r + wave * 1024), 16, 0, 0);
+    }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sk,
                                      (__attribute__((address_space(3))) void *)(slot->k + wave * 1024), 16, 0, 0);
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sv,
@@ -297,7 +313,7 @@ constexpr int kDepth = QCN_MODES_DEPTH;   // 3 .. 5
 constexpr int kBufs = kDepth + 1;
 constexpr int kIdxAhead = 2;
 
-template <bool HAS_EID>
+template <bool HAS_EID, bool BF16>
 __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 {
     static_assert(kBufs >= 4 && kBufs <= 6, "one __shared__ slot per ring position below");
@@ -325,24 +341,37 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 
     // the head's weight fragments: frag[lane][j] = W[16 w + (lane & 15)][32 ks + 8 (lane >> 4) + j]
     half8 wk_hi[4], wk_lo[4], wv_hi[4], wv_lo[4];
+    bf16x8 wk_b[4], wv_b[4];          // bf16 form: [head][wk | wv][ks][lane] fragments, no scaling
+    float usc_k = 1.f, usc_v = 1.f;
+    if constexpr (BF16) {
+        const bf16x8 *wb = reinterpret_cast<const bf16x8 *>(a.wfrag);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const half8 *base = a.wfrag + (size_t)((wave * 2) * 4 + ks) * 2 * 64 + lane;
-        wk_hi[ks] = base[0];
-        wk_lo[ks] = base[64];
-        wv_hi[ks] = base[4 * 2 * 64];
-        wv_lo[ks] = base[4 * 2 * 64 + 64];
+        for (int ks = 0; ks < 4; ++ks) {
+            wk_b[ks] = wb[(size_t)((wave * 2) * 4 + ks) * 64 + lane];
+            wv_b[ks] = wb[(size_t)((wave * 2 + 1) * 4 + ks) * 64 + lane];
+        }
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const half8 *base = a.wfrag + (size_t)((wave * 2) * 4 + ks) * 2 * 64 + lane;
+            wk_hi[ks] = base[0];
+            wk_lo[ks] = base[64];
+            wv_hi[ks] = base[4 * 2 * 64];
+            wv_lo[ks] = base[4 * 2 * 64 + 64];
+        }
+        const float *scales = reinterpret_cast<const float *>(a.wfrag + (size_t)kHeads * 2 * 4 * 2 * 64);
+        usc_k = scales[0];
+        usc_v = scales[1];
     }
-    const float *scales = reinterpret_cast<const float *>(a.wfrag + (size_t)kHeads * 2 * 4 * 2 * 64);
-    const float usc_k = scales[0], usc_v = scales[1];
     const float bias = a.bv[16 * wave + i];
     float *const s_tw = s_t[wave];
     const NodeAddr na = make_node_addr(a, wave, lane);
 
     // per-lane LDS byte offsets inside a slot (tile independent)
+    constexpr int kRhatRow = BF16 ? 256 : kRowBytes;
     int r_off[4], v_off[4];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) r_off[ks] = i * kRowBytes + 16 * ((4 * ks + g) ^ i);              // rhat: row i, chunk 4 ks + g
+    for (int ks = 0; ks < 4; ++ks) r_off[ks] = i * kRhatRow + 16 * ((4 * ks + g) ^ i);               // rhat: row i, chunk 4 ks + g
     const int k_off = i * kRowBytes + 16 * ((4 * wave + g) ^ i);                                      // k: row i, floats 16 w + 4 g ..
 #pragma unroll
     for (int t = 0; t < 4; ++t)                                                                       // v: row 4 g + t, float 16 w + i
@@ -382,6 +411,27 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         f32x4 kx = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
         kk = f32x4{0.f, 0.f, 0.f, 0.f};
         vv = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (BF16) {
+            bf16x8 rb[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) rb[ks] = *reinterpret_cast<const bf16x8 *>(slot->r + r_off[ks]);
+            const f32x4 kf = *reinterpret_cast<const f32x4 *>(slot->k + k_off);
+            float vf[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vf[r] = *reinterpret_cast<const float *>(slot->v + v_off[r]);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                kk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wk_b[ks], rb[ks], kk, 0, 0, 0);
+                vv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(rb[ks], wv_b[ks], vv, 0, 0, 0);
+                between(ks);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                kk[r] += kf[r];
+                vv[r] += vf[r];
+            }
+            return;
+        }
         half8 rh[4], rl[4];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -416,7 +466,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
             if constexpr (J < kDepth) {
                 const Tile t = safe(tl[J]);
                 const TileIdx x = load_tile_idx<HAS_EID>(a, t, wave, lane);
-                issue_tile_dma(a, x, slot_of(ph), wave, lane);
+                issue_tile_dma<BF16>(a, x, slot_of(ph), wave, lane);
                 qring[J] = load_q(a, na, t.row);
                 idx[J] = x;
             }
@@ -453,7 +503,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         const Tile t0 = tl[0], tb = safe(tl[kDepth]), tc = safe(tl[kTiles - 1]);
         const Tile tn = next_tile(a, tl[kTiles - 1], row_end);
         STAMP(0)
-        issue_tile_dma(a, idx[SB], slot_of(std::integral_constant<int, SB>{}), wave, lane);
+        issue_tile_dma<BF16>(a, idx[SB], slot_of(std::integral_constant<int, SB>{}), wave, lane);
         STAMP(1)
         qring[SB] = load_q(a, na, tb.row);
         idx[SC] = load_tile_idx<HAS_EID>(a, tc, wave, lane);
@@ -599,7 +649,7 @@ __global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesAr
     TileIdx x1;
     {
         const TileIdx x0 = load_tile_idx<HAS_EID>(a, t0, wave, lane);
-        issue_tile_dma(a, x0, &s_0, wave, lane);
+        issue_tile_dma<false>(a, x0, &s_0, wave, lane);
         x1 = load_tile_idx<HAS_EID>(a, safe(t1), wave, lane);
     }
     __builtin_amdgcn_s_waitcnt(wait_imm(0));
@@ -614,7 +664,7 @@ __global__ __launch_bounds__(64 * kHeads, 4) void attn_modes_lean_kernel(ModesAr
         Slot *const nxt = S == 0 ? &s_1 : &s_0;
         const Tile tn = next_tile(a, t2, row_end);
         // DMAs of the next tile first, then the loads that may stay in flight over the barrier
-        issue_tile_dma(a, x1, nxt, wave, lane);
+        issue_tile_dma<false>(a, x1, nxt, wave, lane);
         x1 = load_tile_idx<HAS_EID>(a, safe(t2), wave, lane);
 
         const bool first = t0.first;
@@ -723,26 +773,26 @@ extern "C" int qcn_split_rows_f16(const float *x, int64_t n_rows, int scale_log2
 
 extern "C" size_t qcn_attn_modes_pack_bytes(void) { return (size_t)kHeads * 2 * 4 * 2 * 64 * 16 + 2 * sizeof(float); }
 
-extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v, const void *rhat_split,
-                                  const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
-                                  const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
-                                  int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream)
+static int launch_attn_modes(bool bf16, const float *q, const float *k, const float *v, const void *rhat_op,
+                             const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                             const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                             int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream)
 {
     if (n_dst < 0 || n_src < 0 || n_rows < 0 || num_edges < 0 || rep < 1 || rep > 6) return QCN_ERR_INVALID_ARGUMENT;
     if (layout != 1 && layout != 2) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows * rep != n_dst) return QCN_ERR_INVALID_ARGUMENT;
     if (n_dst == 0) return QCN_OK;
     if (!q || !out || !rowptr || !wpack || !bv) return QCN_ERR_INVALID_ARGUMENT;
-    if (num_edges > 0 && (!k || !v || !col || !rhat_split)) return QCN_ERR_INVALID_ARGUMENT;
+    if (num_edges > 0 && (!k || !v || !col || !rhat_op)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_dst >= ((int64_t)1 << 31) || n_src >= ((int64_t)1 << 31) || num_edges >= ((int64_t)1 << 31))
         return QCN_ERR_UNSUPPORTED;
     if (col_shift < 0 || col_shift >= ((int64_t)1 << 31)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_feat_rows < 0 || (!eid && n_feat_rows < num_edges)) return QCN_ERR_INVALID_ARGUMENT;
-    // the kernel addresses q / out, k / v and rhat_split rows by 32-bit byte offsets (512 B per row)
+    // the kernel addresses q / out, k / v and rhat rows by 32-bit byte offsets (at most 512 B per row)
     const int64_t max_rows = (int64_t)1 << 23;
     if (n_dst >= max_rows || n_src >= max_rows || n_feat_rows >= max_rows) return QCN_ERR_UNSUPPORTED;
-    ModesArgs args{q, k, v, reinterpret_cast<const _Float16 *>(rhat_split), rowptr, col, eid,
-                   reinterpret_cast<const half8 *>(wpack), bv, out, (int)n_rows, rep, layout, (int)col_shift, nullptr};
+    ModesArgs args{q, k, v, rhat_op, rowptr, col, eid, reinterpret_cast<const half8 *>(wpack), bv, out, (int)n_rows, rep,
+                   layout, (int)col_shift, nullptr};
 #ifdef QCN_MODES_STAMPS
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long));
@@ -755,20 +805,20 @@ extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v
     if (const char *env = getenv("QCN_MODES_WG_PER_CU")) { const int want = atoi(env); if (want >= 1 && want <= 8) per_cu = want; }
     int64_t grid = n_rows < 256 * per_cu ? n_rows : 256 * per_cu;
     hipStream_t s = qcn_stream(stream);
-    // algorithmic bytes: every base edge is processed once for all rep modes (rhat row + k row + v row + indices)
-    void *token = qcn_prof_begin(QCN_PROF_ATTN_FUSED, 1552.0 * (double)num_edges + 1024.0 * (double)n_dst, s);
     // QCN_MODES_LEAN=1: the two-workgroups-per-CU variant (same results; measured equal on cfg3, kept for A/B runs)
     const char *lean_env = getenv("QCN_MODES_LEAN");
-    const bool lean = lean_env && atoi(lean_env) != 0;
+    const bool lean = !bf16 && lean_env && atoi(lean_env) != 0;
     if (lean) {
         if (eid) hipLaunchKernelGGL((attn_modes_lean_kernel<true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
         else     hipLaunchKernelGGL((attn_modes_lean_kernel<false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+    } else if (bf16) {
+        if (eid) hipLaunchKernelGGL((attn_modes_kernel<true, true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+        else     hipLaunchKernelGGL((attn_modes_kernel<false, true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
     } else {
-        if (eid) hipLaunchKernelGGL((attn_modes_kernel<true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
-        else     hipLaunchKernelGGL((attn_modes_kernel<false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+        if (eid) hipLaunchKernelGGL((attn_modes_kernel<true, false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+        else     hipLaunchKernelGGL((attn_modes_kernel<false, false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
     }
     const bool ok = hipGetLastError() == hipSuccess;
-    qcn_prof_end(token, s);
 #ifdef QCN_MODES_STAMPS
     {
         unsigned long long h[64];
@@ -782,4 +832,24 @@ extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v
     }
 #endif
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
+}
+
+extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v, const void *rhat_split,
+                                  const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                                  const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                                  int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream)
+{
+    return launch_attn_modes(false, q, k, v, rhat_split, rowptr, col, eid, wpack, bv, n_dst, n_src, n_rows, num_edges,
+                             n_feat_rows, rep, layout, col_shift, out, stream);
+}
+
+extern "C" size_t qcn_attn_modes_bf16_pack_bytes(void) { return (size_t)kHeads * 2 * 4 * 64 * 16; }
+
+extern "C" int qcn_attn_modes_bf16(const float *q, const float *k, const float *v, const void *rhat_bf16,
+                                   const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                                   const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                                   int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream)
+{
+    return launch_attn_modes(true, q, k, v, rhat_bf16, rowptr, col, eid, wpack, bv, n_dst, n_src, n_rows, num_edges,
+                             n_feat_rows, rep, layout, col_shift, out, stream);
 }

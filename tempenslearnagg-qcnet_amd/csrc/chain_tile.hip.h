@@ -2,7 +2,8 @@
 // whose work is a CHAIN of 128x128 linear layers with per-row epilogues between them: FourierEmbedding (fourier.hip)
 // and the AttentionLayer node-side blocks (nodeops.hip).
 //
-// Every GEMM is computed transposed, Y^T = W X^T, on the matrix cores, in one of two arithmetic modes (qcn_set_matmul_mode):
+// Every GEMM is computed transposed, Y^T = W X^T, on the matrix cores, in one of three arithmetic modes (the
+// `matmul_mode` argument of the entry points, include/qcnet_hip.h QCN_MATMUL_*):
 //   exact : v_mfma_f32_32x32x2_f32 — exact fp32 fma chains (bitwise an fmaf loop), 64 cycles per 32x32x2 tile step;
 //   split : every fp32 operand is carried as the unevaluated sum hi + lo of two f16 numbers (22 significant bits) after
 //           an exact power-of-two scaling that puts the largest |element| of the row (resp. of the weight matrix) into
@@ -10,7 +11,11 @@
 //           (the dropped lo*lo term is below 2^-22 of the product): three 32-cycle MFMAs per 16 k instead of eight
 //           64-cycle ones.  Element-wise operand error <= max(2^-22 |x|, 2^-29 max|x|) — the result is within a few
 //           fp32 ulps of the exact mode (tests/test_gpu_attention.py::test_split_matmul_error), at ~3x the rate.
-// In both modes:
+//   bf16  : every operand rounded to bf16 (round to nearest even; weights on the host, activations by v_cvt_pk_bf16_f32),
+//           ONE v_mfma_f32_32x32x16_bf16 per 16 k, fp32 accumulation — BASELINE.json configs[3] "bf16 projections".
+//           Biases, rank-1 terms, LayerNorm / ReLU / sigmoid / residuals stay fp32.  A packed matrix is half the size
+//           (32 KiB: it occupies the first half of its 64 KiB slot in global memory and in LDS).
+// In all modes:
 //   * the WEIGHTS are the MFMA A operand (M = output features, four 32-feature tiles),
 //   * the wave's 32 rows are the N dimension: lane (n = lane & 31, h = lane >> 5) only ever holds data of row n.
 // A row vector lives in 64 registers, f32x16 v[4]:  v[t][r] = feature  32 t + (r & 3) + 8 (r >> 2) + 4 h  of row n.
@@ -92,11 +97,16 @@ __host__ inline int chain_skew_mode(int dflt)
     return dflt;
 }
 
+constexpr int kModeExact = QCN_MATMUL_EXACT_F32, kModeSplit = QCN_MATMUL_SPLIT_F16, kModeBf16 = QCN_MATMUL_BF16;
+
+// 1 KiB LDS-DMA pieces of one packed matrix (bf16: half a slot)
+template <int MODE> constexpr int mat_pieces() { return MODE == kModeBf16 ? kMatVec4 / 64 / 2 : kMatVec4 / 64; }
+
 // Start the LDS-DMA copy of one packed matrix into LDS buffer `dst`; every wave of the block copies WAVES-th of it.
-template <int WAVES>
+template <int WAVES, int MODE>
 __device__ __forceinline__ void stage_matrix(const float *__restrict__ packed, f32x4 *dst, int wave, int lane)
 {
-    constexpr int kPerWave = (kMatVec4 / 64) / WAVES;   // 1 KiB pieces per wave
+    constexpr int kPerWave = mat_pieces<MODE>() / WAVES;   // 1 KiB pieces per wave
 #pragma unroll
     for (int i = 0; i < kPerWave; ++i) {
         const int piece = wave * kPerWave + i;
@@ -120,19 +130,22 @@ __device__ __forceinline__ void stage_vectors(const float *__restrict__ src, flo
 using half8 = __attribute__((ext_vector_type(8))) _Float16;
 using half2v = __attribute__((ext_vector_type(2))) _Float16;
 
-// MFMA B operand of one row vector.  exact: the 64 fp32 registers themselves.  split: 2 x 32 registers of packed f16
-// (hi / lo planes) + the row's power-of-two scale and its inverse.
-template <bool SPLIT> struct Operand;
-template <> struct Operand<false> { f32x16 v[4]; };
-template <> struct Operand<true> { half8 hi[8], lo[8]; float sc, usc; };
+using bf16x8 = __attribute__((ext_vector_type(8))) __bf16;
 
-__device__ __forceinline__ void make_operand(Operand<false> &o, const f32x16 (&in)[4])
+// MFMA B operand of one row vector.  exact: the 64 fp32 registers themselves.  split: 2 x 32 registers of packed f16
+// (hi / lo planes) + the row's power-of-two scale and its inverse.  bf16: 32 registers of packed bf16.
+template <int MODE> struct Operand;
+template <> struct Operand<kModeExact> { f32x16 v[4]; };
+template <> struct Operand<kModeSplit> { half8 hi[8], lo[8]; float sc, usc; };
+template <> struct Operand<kModeBf16> { bf16x8 v[8]; };
+
+__device__ __forceinline__ void make_operand(Operand<kModeExact> &o, const f32x16 (&in)[4])
 {
 #pragma unroll
     for (int t = 0; t < 4; ++t) o.v[t] = in[t];
 }
 
-__device__ __forceinline__ void make_operand(Operand<true> &o, const f32x16 (&in)[4])
+__device__ __forceinline__ void make_operand(Operand<kModeSplit> &o, const f32x16 (&in)[4])
 {
     float mx[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -161,10 +174,20 @@ __device__ __forceinline__ void make_operand(Operand<true> &o, const f32x16 (&in
         }
 }
 
-template <int WAVES>
+// bf16: round to nearest even (v_cvt_pk_bf16_f32); register 8 (j & 1) + i of v[j >> 1] -> element i of fragment j, the k
+// order of the split mode's hi plane
+__device__ __forceinline__ void make_operand(Operand<kModeBf16> &o, const f32x16 (&in)[4])
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.v[j][i] = (__bf16)in[j >> 1][8 * (j & 1) + i];
+}
+
+template <int WAVES, int MODE>
 __device__ __forceinline__ void stage_piece(const float *__restrict__ next, f32x4 *next_dst, int wave, int lane, int i)
 {
-    constexpr int kPieces = (kMatVec4 / 64) / WAVES;   // 1 KiB pieces per wave
+    constexpr int kPieces = mat_pieces<MODE>() / WAVES;   // 1 KiB pieces per wave
     const int piece = wave * kPieces + i;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(next + ((size_t)piece * 64 + lane) * 4),
                                      (__attribute__((address_space(3))) void *)(next_dst + piece * 64), 16, 0, 0);
@@ -178,7 +201,7 @@ __device__ __forceinline__ void stage_piece(const float *__restrict__ next, f32x
 // exact: 64 k-steps x 4 tiles; the weight fragment of k-step s + 1 is requested before the MFMAs of k-step s are all
 // issued, so the LDS latency never sits between a wave's MFMAs.
 template <int WAVES>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<false> &in, const f32x4 *w,
+__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeExact> &in, const f32x4 *w,
                                      const float *__restrict__, int lane, const float *__restrict__ next = nullptr,
                                      f32x4 *next_dst = nullptr, int wave = 0)
 {
@@ -192,7 +215,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<false> &in,
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], b, acc[0], 0, 0, 0);
         if (s + 1 < 64) nxt = w[(s + 1) * 64 + lane];
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[1], b, acc[1], 0, 0, 0);
-        if (s % kEvery == 0 && next != nullptr) stage_piece<WAVES>(next, next_dst, wave, lane, s / kEvery);
+        if (s % kEvery == 0 && next != nullptr) stage_piece<WAVES, kModeExact>(next, next_dst, wave, lane, s / kEvery);
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[2], b, acc[2], 0, 0, 0);
         acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[3], b, acc[3], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);   // keep the request-ahead order: hipcc otherwise sinks the reads to their use
@@ -203,7 +226,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<false> &in,
 // 16-byte fragments (8 f16: out = 32 t + (lane & 31), k = the 8 features of registers 8 (j & 1) .. + 7 of v[j >> 1]).
 // The accumulators are moved to the operands' scale and back by two exact power-of-two multiplies.
 template <int WAVES>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<true> &in, const f32x4 *w,
+__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w,
                                      const float *__restrict__ mscale, int lane, const float *__restrict__ next = nullptr,
                                      f32x4 *next_dst = nullptr, int wave = 0)
 {
@@ -234,7 +257,7 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<true> &in, 
 #ifndef QCN_EXP_NO_STAGE
         if (g % kEvery == 0 && next != nullptr) {
 #pragma unroll
-            for (int i = 0; i < kPerSlot; ++i) stage_piece<WAVES>(next, next_dst, wave, lane, (g / kEvery) * kPerSlot + i);
+            for (int i = 0; i < kPerSlot; ++i) stage_piece<WAVES, kModeSplit>(next, next_dst, wave, lane, (g / kEvery) * kPerSlot + i);
         }
 #endif
 #ifndef QCN_EXP_NO_MFMA
@@ -244,6 +267,42 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<true> &in, 
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] *= U;
+}
+
+// bf16: 8 k16-steps x 4 tiles, one MFMA each.  LDS image of a matrix: [k16-step j][tile t][lane] 16-byte fragments (8 bf16:
+// out = 32 t + (lane & 31), k = the 8 features of registers 8 (j & 1) .. + 7 of v[j >> 1]) = 32 KiB.  The four fragments of
+// k16-step j + 1 are requested before the MFMAs of step j issue (registers are plentiful in this mode: the operand is 32).
+template <int WAVES>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeBf16> &in, const f32x4 *w,
+                                     const float *__restrict__, int lane, const float *__restrict__ next = nullptr,
+                                     f32x4 *next_dst = nullptr, int wave = 0)
+{
+    constexpr int kPieces = mat_pieces<kModeBf16>() / WAVES;     // 4 / 8 / 16
+    constexpr int kPerStep = kPieces / 8 > 0 ? kPieces / 8 : 1;  // pieces issued per k16-step
+    constexpr int kEvery = kPieces >= 8 ? 1 : 8 / kPieces;       // ... every kEvery-th step
+    f32x4 cur[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) cur[t] = w[t * 64 + lane];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        f32x4 nxt[4];
+        if (j + 1 < 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) nxt[t] = w[(4 * (j + 1) + t) * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, cur[t]), in.v[j], acc[t], 0, 0, 0);
+        if (j % kEvery == 0 && next != nullptr) {
+#pragma unroll
+            for (int i = 0; i < kPerStep; ++i) stage_piece<WAVES, kModeBf16>(next, next_dst, wave, lane, (j / kEvery) * kPerStep + i);
+        }
+        if (j + 1 < 8) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) cur[t] = nxt[t];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 // per-feature vector (bias, LayerNorm affine, ...) in register layout: 16 broadcast float4 loads
@@ -439,6 +498,33 @@ __device__ __forceinline__ void store_tile2_split(const f32x16 (&v)[4], _Float16
     }
 }
 
+// The row as bf16 (round to nearest even; the operand format of qcn_attn_modes_bf16): dst row = 128 bf16 = 256 B, through the
+// 2 KiB transposition block, one 32-feature block (64 B per row) per pass: lane (n, h) writes its four 8-byte groups
+// (features 32 t + 8 q + 4 h ..) at 16-B chunk q ^ ((n >> 2) & 3) of row n, a global instruction then writes 16 rows x 64 B.
+__device__ __forceinline__ void store_tile2_bf16(const f32x16 (&v)[4], __bf16 *__restrict__ dst, int64_t row0, int64_t n_rows,
+                                                 f32x4 *xpose, int lane)
+{
+    using bf16x4 = __attribute__((ext_vector_type(4))) __bf16;
+    const int n = lane & 31, h = lane >> 5;
+    bf16x4 *const xh = reinterpret_cast<bf16x4 *>(xpose);          // 8-byte units: row n = units 8 n .. 8 n + 7
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            bf16x4 b;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = (__bf16)v[t][4 * q + j];
+            xh[n * 8 + 2 * (q ^ ((n >> 2) & 3)) + h] = b;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = 16 * i + (lane >> 2), c = lane & 3;
+            const f32x4 x = xpose[r * 4 + (c ^ ((r >> 2) & 3))];
+            if (row0 + r < n_rows) *reinterpret_cast<f32x4 *>(dst + (row0 + r) * kC + 32 * t + 8 * c) = x;
+        }
+    }
+}
+
 // LayerNorm over the 128 features of the lane's row (two-pass mean / variance), optional affine and ReLU
 template <bool AFFINE, bool RELU>
 __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restrict__ gamma,
@@ -490,9 +576,8 @@ __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restri
 // a 4- (or 2-) wave block relative to an 8-wave block's 2.0, measured per kernel (MI355X, split mode, microseconds per
 // round of blocks: attn_post 50 / 100 — its four-wave blocks keep their rows in registers —, Fourier in = 3 43 / 57,
 // ln_linear x4 33 / 50).
-__host__ inline int pick_waves(int64_t n_rows, bool split, double small_cost = 1.08, int n_cus = 256)
+__host__ inline int pick_waves(int64_t n_rows, double small_cost = 1.08, int n_cus = 256)
 {
-    (void)split;
     if (const char *env = getenv("QCN_CHAIN_WAVES")) { const int w = atoi(env); if (w == 2 || w == 4 || w == 8) return w; }
     int best = 8;
     double best_cost = 1e300;
@@ -505,18 +590,23 @@ __host__ inline int pick_waves(int64_t n_rows, bool split, double small_cost = 1
     return best;
 }
 
-// launch one of the <SPLIT, WAVES> instantiations through a caller-defined QCN_LAUNCH(S, W)
-#define QCN_CHAIN_DISPATCH(split, waves)                         \
+// launch one of the <MODE, WAVES> instantiations through a caller-defined QCN_LAUNCH(M, W)
+#define QCN_CHAIN_DISPATCH_W(M, waves)                           \
     do {                                                         \
-        if (split) {                                             \
-            if ((waves) == 8) QCN_LAUNCH(true, 8);               \
-            else if ((waves) == 4) QCN_LAUNCH(true, 4);          \
-            else QCN_LAUNCH(true, 2);                            \
-        } else {                                                 \
-            if ((waves) == 8) QCN_LAUNCH(false, 8);              \
-            else if ((waves) == 4) QCN_LAUNCH(false, 4);         \
-            else QCN_LAUNCH(false, 2);                           \
-        }                                                        \
+        if ((waves) == 8) QCN_LAUNCH(M, 8);                      \
+        else if ((waves) == 4) QCN_LAUNCH(M, 4);                 \
+        else QCN_LAUNCH(M, 2);                                   \
     } while (0)
+#define QCN_CHAIN_DISPATCH(mode, waves)                                                    \
+    do {                                                                                   \
+        if ((mode) == QCN_MATMUL_SPLIT_F16) QCN_CHAIN_DISPATCH_W(QCN_MATMUL_SPLIT_F16, waves); \
+        else if ((mode) == QCN_MATMUL_BF16) QCN_CHAIN_DISPATCH_W(QCN_MATMUL_BF16, waves);  \
+        else QCN_CHAIN_DISPATCH_W(QCN_MATMUL_EXACT_F32, waves);                            \
+    } while (0)
+
+__host__ inline bool valid_mode(int mode)
+{
+    return mode == QCN_MATMUL_EXACT_F32 || mode == QCN_MATMUL_SPLIT_F16 || mode == QCN_MATMUL_BF16;
+}
 
 }  // namespace qcn_chain

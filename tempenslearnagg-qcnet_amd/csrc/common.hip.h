@@ -26,11 +26,3 @@ __device__ __forceinline__ unsigned qcn_xcd_remap(unsigned bid, unsigned nblocks
 }
 
 static inline hipStream_t qcn_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
-
-// Optional per-launch hipEvent timing of the hand-written kernels (bench.py roofline leg), see api.hip.
-enum { QCN_PROF_ATTN = 0, QCN_PROF_ATTN_FUSED = 1, QCN_PROF_FOURIER = 2, QCN_PROF_GEMM = 3, QCN_PROF_KINDS = 8 };
-void *qcn_prof_begin(int kind, double alg_units, hipStream_t stream);   // returns nullptr when profiling is off
-void qcn_prof_end(void *token, hipStream_t stream);
-
-// Arithmetic mode of the MFMA chain kernels (api.hip: qcn_set_matmul_mode / qcn_get_matmul_mode).
-int qcn_matmul_mode();

@@ -52,7 +52,7 @@ struct FourierTail {
     int fold;             // 1: the caller folded to_out's Linear into wt / bias (y_j = W'_j relu(LN(sum)) + b'_j): one GEMM less
 };
 
-template <int IN, bool SPLIT, int WAVES>
+template <int IN, int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__restrict__ x,
                                                              const float *__restrict__ extra, int extra_div,
                                                              const float *__restrict__ pack, float *__restrict__ y,
@@ -74,10 +74,10 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     const float *vecs = svec;
     const float *out_vec = vecs + IN * kDimVecs;
     const float *msc = out_vec + kOutVecs;
-    Operand<SPLIT> op;
+    Operand<MODE> op;
 
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
-    stage_matrix<WAVES>(mats, buf0, wave, lane);
+    stage_matrix<WAVES, MODE>(mats, buf0, wave, lane);
     stage_vectors<WAVES>(pack + (size_t)(2 * IN + 1) * kMatFloats, svec, kVecBlock, tid);
     __syncthreads();
     skew_begin(skew);
@@ -178,6 +178,7 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
         if (tail.n_out == 0) {
             if (normalize_out == 2) store_tile2_split(acc_o, reinterpret_cast<_Float16 *>(y), row0, n_rows, xpose, lane, 2048.0f);
+            else if (normalize_out == 3) store_tile2_bf16(acc_o, reinterpret_cast<__bf16 *>(y), row0, n_rows, xpose, lane);
             else store_tile2(acc_o, y, row0, n_rows, xpose, lane);
             skew_end(skew);
             return;
@@ -211,67 +212,65 @@ extern "C" size_t qcn_fourier_pack_floats(int input_dim)
 }
 
 static int launch_fourier(const float *x, int input_dim, const float *extra, int64_t extra_div, const float *pack,
-                          int64_t n_rows, int normalize_out, float *y, const FourierTail &tail, void *stream)
+                          int64_t n_rows, int normalize_out, float *y, const FourierTail &tail, int mode, void *stream)
 {
+    if (!valid_mode(mode)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows < 0 || input_dim < 0 || input_dim > 4) return n_rows < 0 ? QCN_ERR_INVALID_ARGUMENT : QCN_ERR_UNSUPPORTED;
     if (n_rows == 0) return QCN_OK;
     if (!pack || (tail.n_out == 0 && !y) || (input_dim > 0 && !x) || (input_dim == 0 && !extra)) return QCN_ERR_INVALID_ARGUMENT;
-    if (extra_div < 1 || extra_div > 0x7fffffff) return QCN_ERR_INVALID_ARGUMENT;
+    if (extra_div < 1 || extra_div > 0x7fffffff || normalize_out < 0 || normalize_out > 3) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
-    const int waves = pick_waves(n_rows, split, 1.5);
+    const int waves = pick_waves(n_rows, 1.5);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
-    const double flops = (double)n_rows * (input_dim * 2.0 * kC * (129.0 + kC) + 2.0 * kC * kC * (1 - tail.fold + tail.n_out));
-    void *token = qcn_prof_begin(QCN_PROF_FOURIER, flops, s);
 #define QCN_LAUNCH(S, W)                                                                                           \
     hipLaunchKernelGGL((fourier_kernel<QCN_IN, S, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, \
                        n_rows, normalize_out, tail, skew_mode)
     switch (input_dim) {
 #define QCN_IN 0
-    case 0: QCN_CHAIN_DISPATCH(split, waves); break;
+    case 0: QCN_CHAIN_DISPATCH(mode, waves); break;
 #undef QCN_IN
 #define QCN_IN 1
-    case 1: QCN_CHAIN_DISPATCH(split, waves); break;
+    case 1: QCN_CHAIN_DISPATCH(mode, waves); break;
 #undef QCN_IN
 #define QCN_IN 2
-    case 2: QCN_CHAIN_DISPATCH(split, waves); break;
+    case 2: QCN_CHAIN_DISPATCH(mode, waves); break;
 #undef QCN_IN
 #define QCN_IN 3
-    case 3: QCN_CHAIN_DISPATCH(split, waves); break;
+    case 3: QCN_CHAIN_DISPATCH(mode, waves); break;
 #undef QCN_IN
 #define QCN_IN 4
-    default: QCN_CHAIN_DISPATCH(split, waves); break;
+    default: QCN_CHAIN_DISPATCH(mode, waves); break;
 #undef QCN_IN
     }
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
-    qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }
 
 extern "C" int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
-                                     const float *pack, int64_t n_rows, int normalize_out, float *y, void *stream)
+                                     const float *pack, int64_t n_rows, int normalize_out, float *y, int matmul_mode,
+                                     void *stream)
 {
     FourierTail tail{};
-    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, normalize_out, y, tail, stream);
+    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, normalize_out, y, tail, matmul_mode, stream);
 }
 
 extern "C" int qcn_fourier_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
                                       const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
-                                      float *y0, float *y1, float *y2, void *stream)
+                                      float *y0, float *y1, float *y2, int matmul_mode, void *stream)
 {
     if (n_out < 1 || n_out > 3 || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
     FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 0};
-    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, stream);
+    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, matmul_mode, stream);
 }
 
 extern "C" int qcn_fourier_folded_linear_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,
                                              const float *pack, int64_t n_rows, const float *wt, const float *bias, int n_out,
-                                             float *y0, float *y1, float *y2, void *stream)
+                                             float *y0, float *y1, float *y2, int matmul_mode, void *stream)
 {
     if (n_out < 1 || n_out > 3 || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
     if (input_dim < 1) return QCN_ERR_UNSUPPORTED;   // the last in-loop GEMM stages the first folded matrix
     FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 1};
-    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, stream);
+    return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, matmul_mode, stream);
 }

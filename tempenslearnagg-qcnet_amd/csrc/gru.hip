@@ -238,14 +238,16 @@ __global__ __launch_bounds__(256) void gru_split_kernel(const float *__restrict_
 extern "C" size_t qcn_gru_pack_floats(void) { return (size_t)kGruPackFloats + kGruScaleFloats; }
 
 extern "C" int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh_t,
-                           const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, void *stream)
+                           const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, int matmul_mode,
+                           void *stream)
 {
     if (n_seq < 0 || n_steps < 1) return QCN_ERR_INVALID_ARGUMENT;
+    if (matmul_mode != QCN_MATMUL_EXACT_F32 && matmul_mode != QCN_MATMUL_SPLIT_F16) return QCN_ERR_INVALID_ARGUMENT;
     if (n_seq == 0) return QCN_OK;
     if (!gi_r || !gi_z || !gi_n || !whh_t || !b_hh || !h0 || !h_out) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
     const unsigned grid = (unsigned)((n_seq + kRowsPerWave - 1) / kRowsPerWave);
-    if (qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16)
+    if (matmul_mode == QCN_MATMUL_SPLIT_F16)
         hipLaunchKernelGGL(gru_split_kernel, dim3(grid), dim3(256), 0, s, gi_r, gi_z, gi_n, whh_t, b_hh, h0, n_seq, n_steps,
                            h_out);
     else

@@ -19,7 +19,7 @@ namespace {
 
 using namespace qcn_chain;
 
-template <bool SPLIT, int WAVES>
+template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__restrict__ x, int64_t n_rows,
                                                                const float *__restrict__ ln_g,
                                                                const float *__restrict__ ln_b,
@@ -36,13 +36,13 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
     const int64_t row0 = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave;
     f32x4 *const xpose = wlds + 2 * kMatVec4 + wave * 256;
 
-    stage_matrix<WAVES>(wp, wlds, wave, lane);
+    stage_matrix<WAVES, MODE>(wp, wlds, wave, lane);
     f32x16 xv[4];
     load_tile(xv, x, row0, n_rows, xpose, lane);
     if (ln_g != nullptr) layer_norm<true, false>(xv, ln_g, ln_b, h, 1e-5f);
     if (xn_out != nullptr) store_tile(xv, xn_out, row0, n_rows, xpose, lane);
     const float *mscale = wp + (size_t)n_out * kMatFloats;   // {scale, 1 / scale} per matrix
-    Operand<SPLIT> xo;
+    Operand<MODE> xo;
     make_operand(xo, xv);
 #pragma unroll 1
     for (int j = 0; j < n_out; ++j) {
@@ -74,7 +74,7 @@ __device__ unsigned long long g_post_stamps[2][4];
 #define PSTAMP(k)
 #endif
 
-template <bool SPLIT, int WAVES>
+template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__restrict__ agg,
                                                                const float *__restrict__ xn,
                                                                const float *__restrict__ s,
@@ -95,13 +95,13 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     const float *vec = svec;
     const float *msc = vec + kPostVecs;
     const float eps = 1e-5f;
-    Operand<SPLIT> op;
+    Operand<MODE> op;
 
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
 #ifdef QCN_CHAIN_STAMPS
     unsigned long long acc_t[4] = {0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
-    stage_matrix<WAVES>(mats, buf0, wave, lane);
+    stage_matrix<WAVES, MODE>(mats, buf0, wave, lane);
     stage_vectors<WAVES>(pack + (size_t)kPostMats * kMatFloats, svec, kPostVecs + kPostScales, tid);
     __syncthreads();
     skew_begin(skew);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][r] = fmaxf(acc[t][r], 0.f);
-        Operand<SPLIT> hid;
+        Operand<MODE> hid;
         make_operand(hid, acc);
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
         gemm<WAVES>(acc_o, hid, buf0, msc + 2 * (4 + 2 * hb), lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
@@ -213,7 +213,7 @@ struct MlpHeads {
     int n_heads;
 };
 
-template <bool SPLIT, int WAVES>
+template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__restrict__ x, int64_t n_rows,
                                                                const float *__restrict__ pack, MlpHeads hd, int skew_mode)
 {
@@ -229,13 +229,13 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__re
     const float *msc = vecs + hd.n_heads * kMlpVecs;
 
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
-    stage_matrix<WAVES>(pack, wlds, wave, lane);
+    stage_matrix<WAVES, MODE>(pack, wlds, wave, lane);
     stage_vectors<WAVES>(pack + (size_t)n_mats * kMatFloats, svec, hd.n_heads * kMlpVecs + kMlpScales, tid);
     __syncthreads();
     skew_begin(skew);
     f32x16 xv[4];
     load_row(xv, x, rowc, h);
-    Operand<SPLIT> xo;
+    Operand<MODE> xo;
     make_operand(xo, xv);
 #pragma unroll 1
     for (int i = 0; i < hd.n_heads; ++i) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__re
                     wlds + ((2 * i + 1) & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
         layer_norm<true, true>(acc, vec + kC, vec + 2 * kC, h, 1e-5f);
-        Operand<SPLIT> hid;
+        Operand<MODE> hid;
         make_operand(hid, acc);
         load_feature_vec(acc, vec + 3 * kC, h);
         sync_for_stage();
@@ -289,9 +289,9 @@ extern "C" size_t qcn_mlp_heads_pack_floats(int n_heads)
 }
 
 extern "C" int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pack, int n_heads, const int *out_dims,
-                                 float *y0, float *y1, float *y2, void *stream)
+                                 float *y0, float *y1, float *y2, int matmul_mode, void *stream)
 {
-    if (n_rows < 0 || n_heads < 1 || n_heads > kMlpMaxHeads || !out_dims) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_rows < 0 || n_heads < 1 || n_heads > kMlpMaxHeads || !out_dims || !valid_mode(matmul_mode)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows == 0) return QCN_OK;
     if (!x || !pack || !y0 || (n_heads > 1 && !y1) || (n_heads > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
     MlpHeads hd{};
@@ -303,16 +303,13 @@ extern "C" int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pa
     }
     hd.n_heads = n_heads;
     hipStream_t s = qcn_stream(stream);
-    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
-    const int waves = pick_waves(n_rows, split);
+    const int waves = pick_waves(n_rows);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
-    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * n_heads * 2 * 2.0 * kMatFloats, s);
 #define QCN_LAUNCH(S, W) hipLaunchKernelGGL((mlp_heads_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, pack, hd, skew_mode)
-    QCN_CHAIN_DISPATCH(split, waves);
+    QCN_CHAIN_DISPATCH(matmul_mode, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
-    qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }
 
@@ -320,47 +317,41 @@ extern "C" size_t qcn_attn_post_pack_floats(void) { return (size_t)kPostMats * k
 
 extern "C" int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
                                  const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
-                                 float *y3, float *xn_out, void *stream)
+                                 float *y3, float *xn_out, int matmul_mode, void *stream)
 {
-    if (n_rows < 0 || n_out < 1 || n_out > 4) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_rows < 0 || n_out < 1 || n_out > 4 || !valid_mode(matmul_mode)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows == 0) return QCN_OK;
     if (!x || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2) || (n_out > 3 && !y3)) return QCN_ERR_INVALID_ARGUMENT;
     if ((ln_weight == nullptr) != (ln_bias == nullptr)) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
-    const int waves = pick_waves(n_rows, split, 1.32);
+    const int waves = pick_waves(n_rows, 1.32);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
-    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * n_out * 2.0 * kMatFloats, s);
 #define QCN_LAUNCH(S, W)                                                                                           \
     hipLaunchKernelGGL((ln_linear_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, x, n_rows, ln_weight, ln_bias, wt, bias, \
                        n_out, y0, y1, y2, y3, xn_out)
-    QCN_CHAIN_DISPATCH(split, waves);
+    QCN_CHAIN_DISPATCH(matmul_mode, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
-    qcn_prof_end(token, s);
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
 }
 
 extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
-                                 const float *pack, int64_t n_rows, float *out, void *stream)
+                                 const float *pack, int64_t n_rows, float *out, int matmul_mode, void *stream)
 {
-    if (n_rows < 0) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_rows < 0 || !valid_mode(matmul_mode)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows == 0) return QCN_OK;
     if (!agg || !s_proj || !x_res || !pack || !out) return QCN_ERR_INVALID_ARGUMENT;   // xn_dst may be NULL
     if (out == agg || out == xn_dst || out == s_proj || out == x_res) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const bool split = qcn_matmul_mode() == QCN_MATMUL_SPLIT_F16;
-    const int waves = pick_waves(n_rows, split, 1.0);
+    const int waves = pick_waves(n_rows, 1.0);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
-    void *token = qcn_prof_begin(QCN_PROF_GEMM, (double)n_rows * kPostMats * 2.0 * kMatFloats, s);
 #define QCN_LAUNCH(S, W)                                                                                          \
     hipLaunchKernelGGL((attn_post_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, agg, xn_dst, s_proj, x_res, pack, n_rows, \
                        out, skew_mode)
-    QCN_CHAIN_DISPATCH(split, waves);
+    QCN_CHAIN_DISPATCH(matmul_mode, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
-    qcn_prof_end(token, s);
 #ifdef QCN_CHAIN_STAMPS
     {
         unsigned long long h[2][4];

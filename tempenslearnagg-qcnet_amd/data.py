@@ -14,7 +14,8 @@ Collation follows PyG's rule: node stores are concatenated, ``edge_index`` of a
 ``(src, rel, dst)`` store is offset by the cumulative node counts of ``src`` / ``dst``,
 ``num_nodes`` is summed, and every node store gains ``batch`` and ``ptr`` vectors.
 """
-from typing import Any, Dict, Iterable, List, Tuple, Union
+import weakref
+from typing import Any, Dict, Iterable, List, Optional, Tuple, Union
 
 import torch
 
@@ -24,6 +25,57 @@ Key = Union[str, Tuple[str, str, str]]
 _PER_GRAPH_KEYS = ('av_index',)
 
 
+class _Store(dict):
+    """A node / edge store.  Any change of its entries (``data['agent']['position'] = t``, ``del``, ``update`` ...) is new
+    input for the container that owns it: the owner's ready mark and derived-quantity cache are dropped (see
+    ``HeteroData.mark_ready``).  Writes INTO a tensor are caught by the version check of ``HeteroData.ready_event``."""
+
+    __slots__ = ('_owner',)
+
+    def __init__(self, *args, owner=None, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self._owner = weakref.ref(owner) if owner is not None else None
+
+    def _touch(self) -> None:
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None:
+            owner._invalidate()
+
+    def __setitem__(self, key, value) -> None:
+        super().__setitem__(key, value)
+        self._touch()
+
+    def __delitem__(self, key) -> None:
+        super().__delitem__(key)
+        self._touch()
+
+    def update(self, *args, **kwargs) -> None:
+        super().update(*args, **kwargs)
+        self._touch()
+
+    def pop(self, *args):
+        out = super().pop(*args)
+        self._touch()
+        return out
+
+    def popitem(self):
+        out = super().popitem()
+        self._touch()
+        return out
+
+    def clear(self) -> None:
+        super().clear()
+        self._touch()
+
+    def setdefault(self, key, default=None):
+        if key not in self:
+            self[key] = default
+        return self[key]
+
+    def __reduce__(self):
+        return (dict, (dict(self),))
+
+
 class HeteroData:
     """One scenario: a dict of node stores (str keys) and edge stores (3-tuple keys)."""
 
@@ -31,21 +83,25 @@ class HeteroData:
         self._stores: Dict[Key, Dict[str, Any]] = {}
         for key, store in (stores or {}).items():
             if isinstance(store, dict):
-                self._stores[key] = dict(store)
+                self._stores[key] = _Store(store, owner=self)
             else:  # global attribute such as scenario_id
                 self._stores[key] = store
+
+    def _invalidate(self) -> None:
+        self.__dict__.pop('_ready_event', None)
+        self.__dict__.pop('_ready_versions', None)
+        self.__dict__.pop('_derived', None)
 
     def __getitem__(self, key) -> Dict[str, Any]:
         if isinstance(key, list):
             key = tuple(key)
         if key not in self._stores:
-            self._stores[key] = {}
+            self._stores[key] = _Store(owner=self)
         return self._stores[key]
 
     def __setitem__(self, key, value) -> None:
-        self._stores[key] = value
-        self.__dict__.pop('_ready_event', None)      # a replaced store is new input: see mark_ready
-        self.__dict__.pop('_derived', None)
+        self._stores[key] = _Store(value, owner=self) if isinstance(value, dict) else value
+        self._invalidate()                           # a replaced store is new input: see mark_ready
 
     def __contains__(self, key) -> bool:
         return key in self._stores
@@ -63,11 +119,12 @@ class HeteroData:
 
     def _map(self, fn):
         out = self.__class__.__new__(self.__class__)
-        out.__dict__.update({k: v for k, v in self.__dict__.items() if k not in ('_stores', '_ready_event', '_derived')})
+        out.__dict__.update({k: v for k, v in self.__dict__.items()
+                             if k not in ('_stores', '_ready_event', '_ready_versions', '_derived')})
         out._stores = {}
         for key, store in self._stores.items():
             if isinstance(store, dict):
-                out._stores[key] = {n: (fn(v) if torch.is_tensor(v) else v) for n, v in store.items()}
+                out._stores[key] = _Store({n: (fn(v) if torch.is_tensor(v) else v) for n, v in store.items()}, owner=out)
             else:
                 out._stores[key] = fn(store) if torch.is_tensor(store) else store
         return out
@@ -78,13 +135,27 @@ class HeteroData:
             out.mark_ready()
         return out
 
+    def _tensor_versions(self) -> tuple:
+        """(key, name, storage address, version counter) of every input tensor: changes when a tensor is replaced or
+        written in place by any torch op (on any stream)."""
+        out = []
+        for key, store in self._stores.items():
+            if isinstance(store, dict):
+                for name, v in store.items():
+                    if torch.is_tensor(v):
+                        out.append((key, name, v.data_ptr(), v._version))
+            elif torch.is_tensor(store):
+                out.append((key, None, store.data_ptr(), store._version))
+        return tuple(out)
+
     def mark_ready(self):
         """Record, on the current stream, the point from which the inputs of this container are final.  The predictors'
         preparation stream (utils/prep.py) then waits for THIS event instead of for everything enqueued on the main
         stream, so the graph preparation of one batch overlaps the attention / MLP kernels of the previous batch.
-        ``to(device)`` records it (all tensors of the copy are new); whoever writes input tensors in place afterwards
-        (on any stream) must call ``mark_ready()`` again before the next ``predict``.  Containers without the mark are
-        handled conservatively (the preparation stream waits for the main stream)."""
+        ``to(device)`` records it (all tensors of the copy are new).  The mark is dropped — and the preparation stream
+        falls back to waiting for the whole main stream — as soon as a store entry is replaced or an input tensor is
+        written in place (its version counter moved): see ``ready_event``.  Only writes torch cannot see (a raw kernel
+        on ``data_ptr()``) need an explicit ``mark_ready()`` afterwards."""
         dev = None
         for store in self._stores.values():
             for v in (store.values() if isinstance(store, dict) else (store,)):
@@ -93,15 +164,29 @@ class HeteroData:
                     break
             if dev is not None:
                 break
-        self.__dict__.pop('_derived', None)
-        if dev is None:
-            self.__dict__.pop('_ready_event', None)
-        else:
+        self._invalidate()
+        if dev is not None:
             self._ready_event = torch.cuda.current_stream(dev).record_event()
+            self._ready_versions = self._tensor_versions()
         return self
 
-    def derived(self, name: str, fn):
-        """Per-batch quantities computed from the inputs alone (e.g. the focal-track rows), computed once per container."""
+    def ready_event(self) -> Optional['torch.cuda.Event']:
+        """The ready mark if it still describes the inputs (no store entry replaced, no tensor written since), else None."""
+        event = self.__dict__.get('_ready_event')
+        if event is None:
+            return None
+        if self.__dict__.get('_ready_versions') != self._tensor_versions():
+            self._invalidate()
+            return None
+        return event
+
+    def derived(self, name, fn):
+        """Per-batch quantities computed from the inputs alone (e.g. the focal-track rows), computed once per container
+        and recomputed when an input tensor was replaced or written in place since."""
+        versions = self._tensor_versions()
+        if self.__dict__.get('_derived_versions') != versions:
+            self.__dict__['_derived'] = {}
+            self.__dict__['_derived_versions'] = versions
         cache = self.__dict__.setdefault('_derived', {})
         if name not in cache:
             cache[name] = fn()

@@ -25,40 +25,55 @@ class NormalizedEdgeFeatures:
     """Positional embeddings of a relation after the layer-independent half of ``attn_prenorm_r``:
     ``rhat = (r - mean) / sqrt(var + eps)`` per edge, [E_base, 128].  Every AttentionLayer that consumes the
     relation applies only its own affine (folded into its projection weights), so the normalisation is done
-    once per relation instead of once per layer (reference: layers/attention_layer.py:82 in every call)."""
+    once per relation instead of once per layer (reference: layers/attention_layer.py:82 in every call).
+    Held in whichever format it was produced in — fp32 rows, split-f16 rows (``normalized_output='split'``) or bf16 rows
+    (``'bf16'``) — and converted on first use to what a kernel asks for."""
 
-    __slots__ = ('rhat', '_split')
+    __slots__ = ('rhat', '_split', '_bf16')
 
     def __init__(self, rhat: torch.Tensor) -> None:
-        if rhat.dtype == torch.float16:      # already in the split operand format (FourierEmbedding normalized_output='split')
-            self.rhat, self._split = None, rhat
+        self.rhat = self._split = self._bf16 = None
+        if rhat.dtype == torch.float16:      # split operand format (FourierEmbedding normalized_output='split')
+            self._split = rhat
+        elif rhat.dtype == torch.bfloat16:   # bf16 operand format (normalized_output='bf16')
+            self._bf16 = rhat
         else:
-            self.rhat, self._split = rhat, None
+            self.rhat = rhat
 
     @property
     def num_rows(self) -> int:
-        return int((self.rhat if self.rhat is not None else self._split).size(0))
+        return int(next(t for t in (self.rhat, self._split, self._bf16) if t is not None).size(0))
 
     @property
     def split(self) -> torch.Tensor:
         """The same rows as split f16 ([E_base, 256], qcn_split_rows_f16): the operand format of qcn_attn_modes_f32,
         converted once per relation on first use."""
         if self._split is None:
-            self._split = ops.split_rows(self.rhat)
+            self._split = ops.split_rows(self.dense)
         return self._split
+
+    @property
+    def bf16(self) -> torch.Tensor:
+        """The same rows rounded to bf16 ([E_base, 128], round to nearest even): the operand of qcn_attn_modes_bf16."""
+        if self._bf16 is None:
+            self._bf16 = self.dense.bfloat16()
+        return self._bf16
 
     @property
     def dense(self) -> torch.Tensor:
         """fp32 rows [E_base, 128] (the operand of qcn_attn_fused_f32)."""
         if self.rhat is None:
-            sp = self._split.float()
-            self.rhat = ((sp[:, :ops.C] + sp[:, ops.C:]) * 2.0 ** -ops.RHAT_SPLIT_SCALE_LOG2).contiguous()
+            if self._split is not None:
+                sp = self._split.float()
+                self.rhat = ((sp[:, :ops.C] + sp[:, ops.C:]) * 2.0 ** -ops.RHAT_SPLIT_SCALE_LOG2).contiguous()
+            else:
+                self.rhat = self._bf16.float()
         return self.rhat
 
-    def prepare_for(self, rep: int) -> None:
+    def prepare_for(self, rep: int, mode: Optional[int] = None) -> None:
         """Convert ahead of the layers (on the preparation stream) what a relation with ``rep`` queries per row needs."""
         if USE_ATTN_MODES and 1 < rep <= 6:
-            self.split  # noqa: B018  (cached property)
+            self.bf16 if ops._mode(mode) == ops.MATMUL_BF16 else self.split  # noqa: B018  (cached properties)
 
     @classmethod
     def from_raw(cls, r: torch.Tensor, eps: float = 1e-5) -> 'NormalizedEdgeFeatures':
@@ -119,14 +134,15 @@ class AttentionLayer(nn.Module):
         ``pre_*``: chain-packed projection stacks for qcn_ln_linear_f32; ``post``: qcn_attn_post_f32 pack;
         ``pos``: (wk, wv, bv) for qcn_attn_fused_f32 with the attn_prenorm_r affine folded in
         (wk = to_k_r.weight * gamma, wv = to_v_r.weight * gamma, bv = to_v_r.weight @ beta + to_v_r.bias)."""
-        key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        mode = ops.matmul_mode()
+        key = (mode,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
         if key == self._pack_key:
             return self._packs
         C = ops.C
         with torch.no_grad():
             zero = torch.zeros(C, device=self.to_q.weight.device)
-            stack = lambda *lins: ops.pack_chain_matrices([lin.weight for lin in lins])
-            packs = {}
+            stack = lambda *lins: ops.pack_chain_matrices([lin.weight for lin in lins], mode=mode)
+            packs = {'mode': mode}
             packs['pre_src'] = (stack(self.to_k, self.to_v), torch.stack([zero, self.to_v.bias]).contiguous())
             packs['pre_dst'] = (stack(self.to_q, self.to_s),
                                 torch.stack([self.to_q.bias, self.to_s.bias]).contiguous())
@@ -136,7 +152,7 @@ class AttentionLayer(nn.Module):
             w1, w2 = self.ff_mlp[0], self.ff_mlp[3]
             for hb in range(4):
                 mats += [w1.weight[hb * C:(hb + 1) * C, :], w2.weight[:, hb * C:(hb + 1) * C]]
-            mats, scales = ops.pack_chain_set(mats)
+            mats, scales = ops.pack_chain_set(mats, mode=mode)
             mats = [mats]
             vecs = [self.to_g.bias, self.to_out.bias, self.attn_postnorm.weight, self.attn_postnorm.bias,
                     self.ff_prenorm.weight, self.ff_prenorm.bias, w1.bias, w2.bias, self.ff_postnorm.weight,
@@ -148,7 +164,7 @@ class AttentionLayer(nn.Module):
                 packs['pos'] = ((self.to_k_r.weight * gamma.unsqueeze(0)).contiguous(),
                                 (self.to_v_r.weight * gamma.unsqueeze(0)).contiguous(),
                                 (self.to_v_r.weight @ beta + self.to_v_r.bias).contiguous())
-                packs['pos_modes'] = ops.pack_attn_modes(packs['pos'][0], packs['pos'][1])
+                packs['pos_modes'] = ops.pack_attn_modes(packs['pos'][0], packs['pos'][1], mode=mode)
         self._packs, self._pack_key = packs, key
         return packs
 
@@ -162,6 +178,7 @@ class AttentionLayer(nn.Module):
         if self.training and self.dropout > 0:
             raise RuntimeError('AttentionLayer is inference-only: call .eval() (dropout is not implemented)')
         packs = self._kernel_packs()
+        mode = packs['mode']
         single = isinstance(x, torch.Tensor)   # one node set: source and destination share LN(x) (reference :74-75)
         if single:
             x_res = x.contiguous()
@@ -186,18 +203,19 @@ class AttentionLayer(nn.Module):
         # pre: LayerNorm + q/k/v/s projections (one or two launches)
         if not single:
             ln_s, ln_d = self.attn_prenorm_x_src, self.attn_prenorm_x_dst
-            (k, v), _ = ops.ln_linear(x_src, ln_s.weight, ln_s.bias, *packs['pre_src'])
-            (q, s), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'])
+            (k, v), _ = ops.ln_linear(x_src, ln_s.weight, ln_s.bias, *packs['pre_src'], mode=mode)
+            (q, s), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'], mode=mode)
         else:
             ln = self.attn_prenorm_x_src
-            (q, k, v, s), _ = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_all'])
+            (q, k, v, s), _ = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_all'], mode=mode)
         # propagate: gather + segment softmax + weighted scatter-add (one launch)
         if r is not None:
             wk, wv, bv = packs['pos']
-            if 1 < graph.rep <= 6 and graph.layout != ops.LAYOUT_PLAIN and USE_ATTN_MODES:
-                # mode-replicated relation: per-edge projections once per (row, edge) on the matrix cores
-                agg = ops.attn_modes(q, k, v, r.split, graph.rowptr, graph.col, graph.eid, packs['pos_modes'], bv,
-                                     graph.rep, graph.layout, graph.col_shift)
+            if self.uses_attn_modes(graph, n_dst, n_src, r.num_rows):
+                # mode-replicated relation: per-edge projections once per (row, edge) on the matrix cores — bf16 operands
+                # in the bf16 mode (BASELINE.json configs[3]), split f16 (fp32-equivalent) otherwise
+                agg = ops.attn_modes(q, k, v, r.bf16 if mode == ops.MATMUL_BF16 else r.split, graph.rowptr, graph.col,
+                                     graph.eid, packs['pos_modes'], bv, graph.rep, graph.layout, graph.col_shift)
             else:
                 agg = ops.attn_fused(q, k, v, r.dense, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep,
                                      graph.layout,
@@ -208,4 +226,12 @@ class AttentionLayer(nn.Module):
             agg = ops.attn_fwd(q, k, v, None, None, graph.rowptr, graph.col, graph.eid)
         # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)
         # the gate's LN(x_dst) is recomputed inside the kernel (xn_dst = None): cheaper than a [N, 128] round trip
-        return ops.attn_post(agg, None, s, x_res, packs['post'])
+        return ops.attn_post(agg, None, s, x_res, packs['post'], mode=mode)
+
+    @staticmethod
+    def uses_attn_modes(graph: CSRGraph, n_dst: int, n_src: int, n_feat_rows: int) -> bool:
+        """Dispatch of the propagate: mode-replicated relations (2..6 queries per CSR row) go to qcn_attn_modes_* unless a
+        row count reaches 2^23 — that kernel addresses rows by 32-bit byte offsets and would refuse; qcn_attn_fused_f32
+        handles the same graph at any size."""
+        return (USE_ATTN_MODES and 1 < graph.rep <= 6 and graph.layout != ops.LAYOUT_PLAIN
+                and ops.attn_modes_supported(n_dst, n_src, n_feat_rows))

@@ -45,7 +45,8 @@ class FourierEmbedding(nn.Module):
     def packed_weights(self) -> torch.Tensor:
         """Parameters in the layout of include/qcnet_hip.h (qcn_fourier_embed_f32), cached per parameter version."""
         params = list(self.parameters())
-        key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in params)
+        mode = ops.matmul_mode()
+        key = (mode,) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self._pack_key:
             mats, orders, vecs = [], [], []
             with torch.no_grad():
@@ -64,7 +65,7 @@ class FourierEmbedding(nn.Module):
                 mats.append(lin.weight)
                 orders.append(None)
                 vecs += [ln.weight, ln.bias, lin.bias]
-                packed, scales = ops.pack_chain_set(mats, orders)
+                packed, scales = ops.pack_chain_set(mats, orders, mode=mode)
                 self._pack = torch.cat([packed.reshape(-1)] + [p.reshape(-1).float() for p in vecs]
                                        + [ops.scale_table(scales)]).contiguous()
             self._pack_key = key
@@ -78,7 +79,8 @@ class FourierEmbedding(nn.Module):
         """Reference signature plus two keyword extras used by the modules' fast paths:
         ``categorical_repeat`` = R means row n takes ``categorical_embs[...][n // R]`` (the reference materialises
         ``repeat_interleave(R)``, modules/qcnet_agent_encoder.py:109); ``normalized_output`` returns the result
-        row-normalised, i.e. after the layer-independent half of the consumers' ``attn_prenorm_r``."""
+        row-normalised, i.e. after the layer-independent half of the consumers' ``attn_prenorm_r`` (True: fp32 rows;
+        'split' / 'bf16': the operand formats of the mode attention kernel, see ops.fourier_embed)."""
         if continuous_inputs is None and categorical_embs is None:
             raise ValueError('Both continuous_inputs and categorical_embs are None')
         if (continuous_inputs is None) != (self.input_dim == 0):
@@ -90,4 +92,6 @@ class FourierEmbedding(nn.Module):
         x = None
         if continuous_inputs is not None:
             x = continuous_inputs.reshape(-1, self.input_dim).contiguous().float()
-        return ops.fourier_embed(x, self.input_dim, self.packed_weights(), extra, categorical_repeat, normalized_output)
+        mode = ops.matmul_mode()
+        pack = self.packed_weights()
+        return ops.fourier_embed(x, self.input_dim, pack, extra, categorical_repeat, normalized_output, mode=mode)

@@ -39,13 +39,14 @@ class MLPLayer(nn.Module):
         if not 1 <= len(layers) <= 3:
             raise ValueError('one to three heads per launch')
         prm = [p for l in layers for p in l.parameters()]
-        key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in prm)
+        mode = ops.matmul_mode()
+        key = (mode,) + tuple((p.data_ptr(), p._version) for p in prm)
         if cache.get('key') != key:
             with torch.no_grad():
-                cache['pack'] = ops.pack_mlp_heads([l._head() for l in layers])
+                cache['pack'] = ops.pack_mlp_heads([l._head() for l in layers], mode=mode)
             cache['key'] = key
         lead = x.shape[:-1]
-        ys = ops.mlp_heads(x.reshape(-1, ops.C).contiguous().float(), cache['pack'], [l.output_dim for l in layers])
+        ys = ops.mlp_heads(x.reshape(-1, ops.C).contiguous().float(), cache['pack'], [l.output_dim for l in layers], mode=mode)
         return [y.view(*lead, y.size(-1)) for y in ys]
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

@@ -95,16 +95,23 @@ class QCNetDecoder(nn.Module):
         gru = self.traj_emb
         out_lin = self.y_emb.to_out[2]
         prm = (gru.weight_ih_l0, gru.weight_hh_l0, gru.bias_ih_l0, gru.bias_hh_l0, self.traj_emb_h0, out_lin.weight, out_lin.bias)
-        key = (ops.matmul_mode(),) + tuple((p.data_ptr(), p._version) for p in prm)
+        mode = ops.matmul_mode()
+        key = (mode,) + tuple((p.data_ptr(), p._version) for p in prm)
         if key != getattr(self, '_gru_key', None):
             C = self.hidden_dim
             with torch.no_grad():
-                # y_emb's last Linear feeds the GRU's input half directly (:255-257): folded into it, one GEMM per row less
-                w_f, b_f = ops.fold_linear(list(gru.weight_ih_l0.view(3, C, C)), list(gru.bias_ih_l0.view(3, C)),
-                                           out_lin.weight, out_lin.bias)
-                wih_t = ops.pack_chain_matrices(w_f)
-                self._gru_pack = (wih_t, b_f, ops.pack_gru_whh(gru.weight_hh_l0, self.traj_emb_h0),
-                                  gru.bias_hh_l0.contiguous(), self.traj_emb_h0.reshape(-1).contiguous())
+                # y_emb's last Linear feeds the GRU's input half directly (:255-257): folded into it, one GEMM per row less.
+                # Not in the bf16 mode: there every Linear of the reference multiplies its own bf16-rounded operands (the
+                # mode's contract, include/qcnet_hip.h), and a folded product would round differently.
+                fold = mode != ops.MATMUL_BF16
+                if fold:
+                    w_f, b_f = ops.fold_linear(list(gru.weight_ih_l0.view(3, C, C)), list(gru.bias_ih_l0.view(3, C)),
+                                               out_lin.weight, out_lin.bias)
+                else:
+                    w_f, b_f = list(gru.weight_ih_l0.view(3, C, C)), gru.bias_ih_l0.view(3, C).contiguous()
+                wih_t = ops.pack_chain_matrices(w_f, mode=mode)
+                self._gru_pack = (wih_t, b_f, ops.pack_gru_whh(gru.weight_hh_l0, self.traj_emb_h0, mode=mode),
+                                  gru.bias_hh_l0.contiguous(), self.traj_emb_h0.reshape(-1).contiguous(), mode, fold)
             self._gru_key = key
         return self._gru_pack
 
@@ -172,7 +179,9 @@ class QCNetDecoder(nn.Module):
             pos_m = agent['position'][:, T - 1 + ts, :2].contiguous()
             head_m = agent['heading'][:, T - 1 + ts].contiguous()
             # the three mode relations are consumed by qcn_attn_modes_f32 only: embeddings straight in its operand format
-            r_fmt = 'split' if (attention_layer.USE_ATTN_MODES and 1 < K <= 6 and os.environ.get('QCN_R_SPLIT_FUSED', '1') != '0') else True
+            r_fmt = True
+            if attention_layer.USE_ATTN_MODES and 1 < K <= 6 and os.environ.get('QCN_R_SPLIT_FUSED', '1') != '0':
+                r_fmt = 'bf16' if ops.matmul_mode() == ops.MATMUL_BF16 else 'split'
             mask_src = agent['valid_mask'][:, ts:T + ts].clone()
             mask_src[:, :T - self.num_t2m_steps] = False
             mask_dst = agent['predict_mask'].any(dim=-1, keepdim=True).repeat(1, K)
@@ -238,10 +247,10 @@ class QCNetDecoder(nn.Module):
 
         # trajectory re-encoding: Fourier embedding of the proposed way-points, GRU over the Tf steps, last hidden state
         # (reference :255-257); row n * Tf + t of the embedding is step t of mode query n
-        wih_t, b_ih, whh, b_hh, h0 = self._gru_packs()
+        wih_t, b_ih, whh, b_hh, h0, mm_mode, fold = self._gru_packs()
         gi = ops.fourier_linear(loc_propose_pos.detach().reshape(-1, OD).contiguous().float(), OD,
-                                self.y_emb.packed_weights(), wih_t, b_ih, folded=True)   # y_emb + the GRU's input half, one launch
-        m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0)
+                                self.y_emb.packed_weights(), wih_t, b_ih, folded=fold, mode=mm_mode)   # y_emb + the GRU's input half, one launch
+        m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0, mode=mm_mode)
         m = self._fuse_modes(m, temporal_m)
         m = self._cross_stack('refine', m, *graphs)
 

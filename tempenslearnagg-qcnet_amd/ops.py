@@ -1,17 +1,54 @@
-"""Tensor-level wrappers over the C ABI (include/qcnet_hip.h).
+"""PyTorch custom ops over the C ABI (include/qcnet_hip.h).
 
-Each wrapper validates shapes / dtypes / devices on the host before a kernel sees a pointer (a kernel that
-faults can take the whole GPU host down), allocates outputs and workspaces with torch (plumbing only) and
-launches on torch's current stream.  No wrapper has a CPU or eager fallback.
+Every kernel entry point is registered with the dispatcher as ``torch.ops.qcnet_hip.<name>`` (``torch.library``):
+* the ``CUDA``-key implementation (ROCm tensors carry that key) validates shapes / dtypes / devices on the host before a
+  kernel sees a pointer (a kernel that faults can take the whole GPU host down), allocates outputs and workspaces with
+  torch (plumbing only) and launches through ``libqcnet_hip.so`` on torch's current stream;
+* a fake (meta) implementation gives output shapes, so the ops trace under FakeTensor / ``torch.compile``;
+* the ``CPU`` key REFUSES loudly: the hot path has no CPU or eager fallback (the CPU restatement lives in ``oracle/`` and
+  is test infrastructure only).
+The functions of this module are the typed Python face of those ops (defaults, argument normalisation) and the host-side
+weight packers.  The arithmetic mode of the MFMA chain kernels is an ARGUMENT of every call (the library keeps no state);
+``matmul_mode()`` / ``set_matmul_mode()`` hold the process default the layers use when none is given.
 """
 import ctypes
-from typing import Optional, Tuple
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
 from . import _lib
 
 C = 128  # QCN_CHANNELS
+
+_LIBRARY = torch.library.Library('qcnet_hip', 'DEF')
+OP_NAMES: List[str] = []
+
+
+def _register(name: str, schema: str, fake=None):
+    """Decorator: define ``qcnet_hip::<name><schema>``, register the decorated function for the CUDA key, a refusing CPU
+    kernel, and ``fake`` as the meta implementation."""
+    def deco(fn):
+        _LIBRARY.define(name + schema)
+        _LIBRARY.impl(name, fn, 'CUDA')
+
+        def refuse(*args, **kwargs):
+            raise _lib.QcnError('qcnet_hip::%s got CPU tensors: the QCNet hot path runs on the GPU only (no CPU fallback)'
+                                % name)
+        _LIBRARY.impl(name, refuse, 'CPU')
+        if fake is not None:
+            torch.library.register_fake('qcnet_hip::' + name, fake, lib=_LIBRARY)
+        OP_NAMES.append(name)
+        return fn
+    return deco
+
+
+def _op(name: str):
+    return getattr(torch.ops.qcnet_hip, name)
+
+
+def _dyn():
+    return torch.library.get_ctx().new_dynamic_size()
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -41,6 +78,10 @@ def _require(t: torch.Tensor, name: str, dtype: torch.dtype, device: torch.devic
 # ------------------------------------------------------------------------------------------------
 # radius search
 # ------------------------------------------------------------------------------------------------
+def _radius_pairs_fake(x, y, r, ptr_x, ptr_y, max_num_neighbors, drop_self, mask_x, mask_y, y_first):
+    return x.new_empty((2, _dyn()), dtype=torch.int64), x.new_empty((y.size(0) + 1,), dtype=torch.int64)
+
+
 def radius_pairs(x: torch.Tensor, y: torch.Tensor, r: float, ptr_x: torch.Tensor, ptr_y: torch.Tensor,
                  max_num_neighbors: int, drop_self: bool = False, mask_x: Optional[torch.Tensor] = None,
                  mask_y: Optional[torch.Tensor] = None, y_first: bool = True
@@ -51,6 +92,13 @@ def radius_pairs(x: torch.Tensor, y: torch.Tensor, r: float, ptr_x: torch.Tensor
     ``y_first`` else (x, y); pairs are grouped by ascending y, ``offset`` is the CSR row pointer over y.
     Costs one host synchronisation (E must be known to allocate the output).
     """
+    return _op('radius_pairs')(x, y, float(r), ptr_x, ptr_y, int(max_num_neighbors), bool(drop_self), mask_x, mask_y,
+                               bool(y_first))
+
+
+@_register('radius_pairs', '(Tensor x, Tensor y, float r, Tensor ptr_x, Tensor ptr_y, int max_num_neighbors, bool drop_self, '
+           'Tensor? mask_x, Tensor? mask_y, bool y_first) -> (Tensor, Tensor)', _radius_pairs_fake)
+def _radius_pairs(x, y, r, ptr_x, ptr_y, max_num_neighbors, drop_self, mask_x, mask_y, y_first):
     dev = x.device
     dim = x.size(1) if x.dim() == 2 else -1
     _require(x, 'x', torch.float32, dev, (None, dim))
@@ -95,6 +143,17 @@ def radius_pairs(x: torch.Tensor, y: torch.Tensor, r: float, ptr_x: torch.Tensor
 # ------------------------------------------------------------------------------------------------
 def csr_build(edge_index: torch.Tensor, n_dst: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Stable destination sort of a COO edge list → (rowptr int32 [n_dst+1], col int32 [E], eid int32 [E])."""
+    return _op('csr_build')(edge_index, int(n_dst))
+
+
+def _csr_build_fake(edge_index, n_dst):
+    e = edge_index.size(1)
+    mk = lambda n: edge_index.new_empty((n,), dtype=torch.int32)
+    return mk(n_dst + 1), mk(e), mk(e)
+
+
+@_register('csr_build', '(Tensor edge_index, int n_dst) -> (Tensor, Tensor, Tensor)', _csr_build_fake)
+def _csr_build(edge_index, n_dst):
     dev = edge_index.device
     _require(edge_index, 'edge_index', torch.int64, dev, (2, None))
     num_edges = edge_index.size(1)
@@ -118,6 +177,12 @@ def csr_build_static(edge_index: torch.Tensor, n_dst: int, rowptr: torch.Tensor,
     """qcn_csr_build_static: csr_build into CALLER-provided outputs with the sort workspace inside the library — the call
     allocates nothing (for code under HIP graph capture / serving loops).  At most csr_static_max_edges() edges; calls
     that overlap on one GPU race (they share the library's per-GPU scratch array)."""
+    _op('csr_build_static')(edge_index, int(n_dst), rowptr, col, eid)
+
+
+@_register('csr_build_static', '(Tensor edge_index, int n_dst, Tensor(a!) rowptr, Tensor(b!) col, Tensor(c!) eid) -> ()',
+           lambda edge_index, n_dst, rowptr, col, eid: None)
+def _csr_build_static(edge_index, n_dst, rowptr, col, eid):
     dev = edge_index.device
     _require(edge_index, 'edge_index', torch.int64, dev, (2, None))
     num_edges = edge_index.size(1)
@@ -139,6 +204,12 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kr: Optional[tor
              vr: Optional[torch.Tensor], rowptr: torch.Tensor, col: torch.Tensor,
              eid: Optional[torch.Tensor]) -> torch.Tensor:
     """qcn_attn_fwd_f32: gather + segment softmax + weighted scatter-add, [n_dst, 128] fp32."""
+    return _op('attn_fwd')(q, k, v, kr, vr, rowptr, col, eid)
+
+
+@_register('attn_fwd', '(Tensor q, Tensor k, Tensor v, Tensor? kr, Tensor? vr, Tensor rowptr, Tensor col, Tensor? eid) -> Tensor',
+           lambda q, k, v, kr, vr, rowptr, col, eid: torch.empty_like(q))
+def _attn_fwd(q, k, v, kr, vr, rowptr, col, eid):
     dev = q.device
     n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
     _require(q, 'q', torch.float32, dev, (n_dst, C))
@@ -154,14 +225,21 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, kr: Optional[tor
     if eid is not None:
         _require(eid, 'eid', torch.int32, dev, (num_edges,))
     out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
+    tok = _prof_begin(PROF_ATTN, (2064.0 if kr is not None else 1040.0) * num_edges + 1024.0 * n_dst, dev)
     _lib.check(_lib.lib().qcn_attn_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(kr), _ptr(vr), _ptr(rowptr), _ptr(col),
                                            _ptr(eid), n_dst, n_src, num_edges, _ptr(out), _stream(dev)),
                'qcn_attn_fwd_f32')
+    _prof_end(tok, dev)
     return out
 
 
 def row_normalize(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
     """qcn_row_normalize_f32: (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine)."""
+    return _op('row_normalize')(x, float(eps))
+
+
+@_register('row_normalize', '(Tensor x, float eps) -> Tensor', lambda x, eps: torch.empty_like(x))
+def _row_normalize(x, eps):
     dev = x.device
     _require(x, 'x', torch.float32, dev, (None, C))
     y = torch.empty_like(x)
@@ -182,17 +260,33 @@ def chain_feature_order(device=None) -> torch.Tensor:
     return (32 * (s >> 4) + (r & 3) + 8 * (r >> 2) + 4 * h).to(device)
 
 
-MATMUL_EXACT_F32, MATMUL_SPLIT_F16 = 0, 1
+MATMUL_EXACT_F32, MATMUL_SPLIT_F16, MATMUL_BF16 = 0, 1, 2
+MATMUL_MODE_NAMES = {MATMUL_EXACT_F32: 'exact-f32', MATMUL_SPLIT_F16: 'split-f16x3', MATMUL_BF16: 'bf16'}
 CHAIN_MATRIX_FLOATS = C * C
+
+# Process default of the Python layer (QCN_MATMUL_MODE=exact|split|bf16; QCN_MATMUL_EXACT_F32=1 is the old spelling).  The
+# C library itself is stateless: every chain entry point takes the mode as an argument.
+_DEFAULT_MODE = {'exact': MATMUL_EXACT_F32, 'split': MATMUL_SPLIT_F16, 'bf16': MATMUL_BF16}[
+    os.environ.get('QCN_MATMUL_MODE', 'exact' if os.environ.get('QCN_MATMUL_EXACT_F32', '0') == '1' else 'split')]
 
 
 def matmul_mode() -> int:
-    """Arithmetic mode of the MFMA chain kernels (include/qcnet_hip.h: QCN_MATMUL_*)."""
-    return int(_lib.lib().qcn_get_matmul_mode())
+    """Default arithmetic mode of the MFMA chain kernels (include/qcnet_hip.h: QCN_MATMUL_*) for calls that name none."""
+    return _DEFAULT_MODE
 
 
 def set_matmul_mode(mode: int) -> None:
-    _lib.check(_lib.lib().qcn_set_matmul_mode(int(mode)), 'qcn_set_matmul_mode')
+    global _DEFAULT_MODE
+    if int(mode) not in MATMUL_MODE_NAMES:
+        raise ValueError('unknown matmul mode %r' % (mode,))
+    _DEFAULT_MODE = int(mode)
+
+
+def _mode(mode: Optional[int]) -> int:
+    mode = _DEFAULT_MODE if mode is None else int(mode)
+    if mode not in MATMUL_MODE_NAMES:
+        raise ValueError('unknown matmul mode %r' % (mode,))
+    return mode
 
 
 def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = None,
@@ -203,8 +297,7 @@ def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = N
     :func:`chain_feature_order` (the operand is a register-resident row vector)."""
     if tuple(weight.shape) != (C, C):
         raise ValueError('pack_chain_matrix expects a [128, 128] weight, got %s' % (tuple(weight.shape),))
-    if mode is None:
-        mode = matmul_mode()
+    mode = _mode(mode)
     dev = weight.device
     if in_index is None:
         key = str(dev)
@@ -219,6 +312,13 @@ def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = N
     if mode == MATMUL_EXACT_F32:
         packed = w[out_index.view(1, 1, 32, 4), in_index.view(64, 2, 1, 1)]          # P[s, h, m, t]
         return packed.reshape(-1).contiguous(), torch.ones(2, dtype=torch.float32, device=dev)
+    if mode == MATMUL_BF16:
+        kin = in_index.view(8, 8, 2).permute(0, 2, 1)                                 # [j, h, i] = in_index[8 j + i, h]
+        rows = out_index.t().reshape(1, 4, 1, 32, 1)                                  # [., t, ., m, .]
+        cols = kin.reshape(8, 1, 2, 1, 8)                                             # [j, ., h, ., i]
+        frag = w.bfloat16()[rows, cols].contiguous().view(-1).view(torch.float32)     # [j, t, lane = 32 h + m, i], RNE
+        packed = torch.cat([frag, frag.new_zeros(CHAIN_MATRIX_FLOATS - frag.numel())])
+        return packed.contiguous(), torch.ones(2, dtype=torch.float32, device=dev)
     if mode != MATMUL_SPLIT_F16:
         raise ValueError('unknown matmul mode %r' % (mode,))
     _, e = torch.frexp(w.abs().max())                   # max|W| = f * 2^e, f in [1/2, 1)
@@ -258,36 +358,74 @@ def scale_table(scales: torch.Tensor, size: int = 32) -> torch.Tensor:
 
 
 def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor, extra: Optional[torch.Tensor] = None,
-                  extra_div: int = 1, normalize_out: bool = False, n_rows: Optional[int] = None) -> torch.Tensor:
-    """qcn_fourier_embed_f32: the whole FourierEmbedding forward; ``pack`` from ``pack_fourier_weights``."""
-    dev = pack.device
+                  extra_div: int = 1, normalize_out=False, n_rows: Optional[int] = None,
+                  mode: Optional[int] = None) -> torch.Tensor:
+    """qcn_fourier_embed_f32: the whole FourierEmbedding forward; ``pack`` from ``FourierEmbedding.packed_weights`` for the
+    same ``mode``.  ``normalize_out``: False / True (row-normalised) / 'split' (row-normalised split-f16 rows, the operand
+    of attn_modes) / 'bf16' (row-normalised bf16 rows [n, 128], the operand of attn_modes in the bf16 mode)."""
+    if input_dim == 0 and extra is None:
+        raise ValueError('Both continuous_inputs and categorical_embs are None')
     if input_dim > 0:
-        _require(x, 'continuous_inputs', torch.float32, dev, (None, input_dim))
         n_rows = x.size(0)
     elif n_rows is None:
         n_rows = extra.size(0) * extra_div
+    norm = {'split': 2, 'bf16': 3}.get(normalize_out, int(bool(normalize_out)))
+    return _op('fourier_embed')(x, int(input_dim), pack, extra, int(extra_div), norm, int(n_rows), _mode(mode))
+
+
+def _fourier_flops(n_rows: int, input_dim: int, tail_mats: int) -> float:
+    return float(n_rows) * (input_dim * 2.0 * C * (129.0 + C) + 2.0 * C * C * tail_mats)
+
+
+def _fourier_embed_fake(x, input_dim, pack, extra, extra_div, normalize_out, n_rows, mode):
+    if normalize_out == 2:
+        return pack.new_empty((n_rows, 2 * C), dtype=torch.float16)
+    if normalize_out == 3:
+        return pack.new_empty((n_rows, C), dtype=torch.bfloat16)
+    return pack.new_empty((n_rows, C))
+
+
+@_register('fourier_embed', '(Tensor? x, int input_dim, Tensor pack, Tensor? extra, int extra_div, int normalize_out, int n_rows, '
+           'int mode) -> Tensor', _fourier_embed_fake)
+def _fourier_embed(x, input_dim, pack, extra, extra_div, normalize_out, n_rows, mode):
+    dev = pack.device
+    if input_dim > 0:
+        _require(x, 'continuous_inputs', torch.float32, dev, (n_rows, input_dim))
     need = _lib.lib().qcn_fourier_pack_floats(int(input_dim))
     _require(pack, 'pack', torch.float32, dev, (need,))
     if extra is not None:
         _require(extra, 'categorical embedding sum', torch.float32, dev, ((n_rows + extra_div - 1) // extra_div, C))
     elif input_dim == 0:
         raise ValueError('Both continuous_inputs and categorical_embs are None')
-    split = normalize_out == 'split'        # row-normalised AND in the split-f16 operand format of attn_modes
-    if split:
+    if normalize_out == 2:         # row-normalised AND in the split-f16 operand format of attn_modes
         y = torch.empty(n_rows, 2 * C, dtype=torch.float16, device=dev)
+    elif normalize_out == 3:       # ... in its bf16 operand format
+        y = torch.empty(n_rows, C, dtype=torch.bfloat16, device=dev)
     else:
         y = torch.empty(n_rows, C, dtype=torch.float32, device=dev)
+    tok = _prof_begin(PROF_FOURIER, _fourier_flops(n_rows, input_dim, 1), dev)
     _lib.check(_lib.lib().qcn_fourier_embed_f32(_ptr(x) if input_dim > 0 else None, int(input_dim), _ptr(extra),
-                                                int(extra_div), _ptr(pack), n_rows, 2 if split else int(bool(normalize_out)),
-                                                _ptr(y), _stream(dev)), 'qcn_fourier_embed_f32')
+                                                int(extra_div), _ptr(pack), n_rows, int(normalize_out), _ptr(y), int(mode),
+                                                _stream(dev)), 'qcn_fourier_embed_f32')
+    _prof_end(tok, dev)
     return y
 
 
 def fourier_linear(x: torch.Tensor, input_dim: int, pack: torch.Tensor, wt: torch.Tensor, bias: Optional[torch.Tensor],
-                   folded: bool = False):
+                   folded: bool = False, mode: Optional[int] = None) -> List[torch.Tensor]:
     """qcn_fourier_linear_f32: [W_j FourierEmbedding(x) + b_j] for the n_out <= 3 layers of ``wt`` (pack_chain_matrices).
     ``folded``: ``wt`` / ``bias`` already contain the embedding's last Linear (qcn_fourier_folded_linear_f32,
     :func:`fold_linear`)."""
+    return list(_op('fourier_linear')(x, int(input_dim), pack, wt, bias, bool(folded), _mode(mode)))
+
+
+def _fourier_linear_fake(x, input_dim, pack, wt, bias, folded, mode):
+    return [x.new_empty((x.size(0), C)) for _ in range(wt.numel() // (C * C + 2))]
+
+
+@_register('fourier_linear', '(Tensor x, int input_dim, Tensor pack, Tensor wt, Tensor? bias, bool folded, int mode) -> Tensor[]',
+           _fourier_linear_fake)
+def _fourier_linear(x, input_dim, pack, wt, bias, folded, mode):
     dev = pack.device
     _require(x, 'continuous_inputs', torch.float32, dev, (None, input_dim))
     n = x.size(0)
@@ -301,8 +439,11 @@ def fourier_linear(x: torch.Tensor, input_dim: int, pack: torch.Tensor, wt: torc
     ys = [torch.empty(n, C, dtype=torch.float32, device=dev) for _ in range(n_out)]
     yp = [_ptr(y) for y in ys] + [None] * (3 - n_out)
     fn = _lib.lib().qcn_fourier_folded_linear_f32 if folded else _lib.lib().qcn_fourier_linear_f32
+    tok = _prof_begin(PROF_FOURIER, _fourier_flops(n, input_dim, n_out + (0 if folded else 1)), dev)
     _lib.check(fn(_ptr(x), int(input_dim), None, 1, _ptr(pack), n, _ptr(wt), _ptr(bias), n_out,
-                  yp[0], yp[1], yp[2], _stream(dev)), 'qcn_fourier_folded_linear_f32' if folded else 'qcn_fourier_linear_f32')
+                  yp[0], yp[1], yp[2], int(mode), _stream(dev)),
+               'qcn_fourier_folded_linear_f32' if folded else 'qcn_fourier_linear_f32')
+    _prof_end(tok, dev)
     return ys
 
 
@@ -316,10 +457,21 @@ def fold_linear(weights, biases, w_inner: torch.Tensor, b_inner: torch.Tensor):
 
 
 def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optional[torch.Tensor], wt: torch.Tensor,
-              bias: Optional[torch.Tensor], want_xn: bool = False):
+              bias: Optional[torch.Tensor], want_xn: bool = False, mode: Optional[int] = None):
     """qcn_ln_linear_f32: ([y_0 .. y_{n_out-1}], xn or None) with y_j = W_j LayerNorm(x) + b_j; ``wt`` is the stack
     of chain-packed weights and their scale pairs, n_out * (16384 + 2) floats (:func:`pack_chain_matrices`, made for
-    the matmul mode in force), ``bias`` [n_out, 128] or None."""
+    the same ``mode``), ``bias`` [n_out, 128] or None."""
+    outs = list(_op('ln_linear')(x, ln_weight, ln_bias, wt, bias, bool(want_xn), _mode(mode)))
+    return (outs[:-1], outs[-1]) if want_xn else (outs, None)
+
+
+def _ln_linear_fake(x, ln_weight, ln_bias, wt, bias, want_xn, mode):
+    return [torch.empty_like(x) for _ in range(wt.numel() // (C * C + 2) + int(want_xn))]
+
+
+@_register('ln_linear', '(Tensor x, Tensor? ln_weight, Tensor? ln_bias, Tensor wt, Tensor? bias, bool want_xn, int mode) -> Tensor[]',
+           _ln_linear_fake)
+def _ln_linear(x, ln_weight, ln_bias, wt, bias, want_xn, mode):
     dev = x.device
     n = x.size(0)
     n_out = wt.numel() // (C * C + 2)
@@ -335,15 +487,24 @@ def ln_linear(x: torch.Tensor, ln_weight: Optional[torch.Tensor], ln_bias: Optio
     ys = [torch.empty(n, C, dtype=torch.float32, device=dev) for _ in range(n_out)]
     xn = torch.empty(n, C, dtype=torch.float32, device=dev) if want_xn else None
     yp = [_ptr(y) for y in ys] + [None] * (4 - n_out)
+    tok = _prof_begin(PROF_GEMM, float(n) * n_out * 2.0 * C * C, dev)
     _lib.check(_lib.lib().qcn_ln_linear_f32(_ptr(x), n, _ptr(ln_weight), _ptr(ln_bias), _ptr(wt), _ptr(bias), n_out,
-                                            yp[0], yp[1], yp[2], yp[3], _ptr(xn), _stream(dev)), 'qcn_ln_linear_f32')
-    return ys, xn
+                                            yp[0], yp[1], yp[2], yp[3], _ptr(xn), int(mode), _stream(dev)),
+               'qcn_ln_linear_f32')
+    _prof_end(tok, dev)
+    return ys + ([xn] if want_xn else [])
 
 
 def attn_post(agg: torch.Tensor, xn_dst: Optional[torch.Tensor], s_proj: torch.Tensor, x_res: torch.Tensor,
-              pack: torch.Tensor) -> torch.Tensor:
+              pack: torch.Tensor, mode: Optional[int] = None) -> torch.Tensor:
     """qcn_attn_post_f32: gate/update + to_out + post-norm residual + feed-forward block of one AttentionLayer.
     ``xn_dst`` None: the kernel recomputes attn_prenorm_x_dst(x_res) from the affine stored in ``pack``."""
+    return _op('attn_post')(agg, xn_dst, s_proj, x_res, pack, _mode(mode))
+
+
+@_register('attn_post', '(Tensor agg, Tensor? xn_dst, Tensor s_proj, Tensor x_res, Tensor pack, int mode) -> Tensor',
+           lambda agg, xn_dst, s_proj, x_res, pack, mode: torch.empty_like(agg))
+def _attn_post(agg, xn_dst, s_proj, x_res, pack, mode):
     dev = agg.device
     n = agg.size(0)
     for name, t in (('agg', agg), ('xn_dst', xn_dst), ('s_proj', s_proj), ('x_res', x_res)):
@@ -352,8 +513,10 @@ def attn_post(agg: torch.Tensor, xn_dst: Optional[torch.Tensor], s_proj: torch.T
         _require(t, name, torch.float32, dev, (n, C))
     _require(pack, 'pack', torch.float32, dev, (_lib.lib().qcn_attn_post_pack_floats(),))
     out = torch.empty(n, C, dtype=torch.float32, device=dev)
+    tok = _prof_begin(PROF_GEMM, float(n) * 11 * 2.0 * C * C, dev)
     _lib.check(_lib.lib().qcn_attn_post_f32(_ptr(agg), _ptr(xn_dst), _ptr(s_proj), _ptr(x_res), _ptr(pack), n, _ptr(out),
-                                            _stream(dev)), 'qcn_attn_post_f32')
+                                            int(mode), _stream(dev)), 'qcn_attn_post_f32')
+    _prof_end(tok, dev)
     return out
 
 
@@ -361,6 +524,20 @@ def rel_geometry(pos_src: torch.Tensor, pos_dst: torch.Tensor, head_src: torch.T
                  edge_index: torch.Tensor, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
     """qcn_rel_geometry_f32: [E, 3 (4 with ``extra``)] relative-geometry rows of an edge list ([2, E] int64, row 0 indexes
     the ``*_src`` tensors, row 1 the ``*_dst`` tensors; the edge lists come from the graph builders and are in range)."""
+    if edge_index.dim() != 2 or edge_index.size(0) != 2 or edge_index.dtype != torch.int64:
+        raise ValueError('edge_index must be [2, E] int64')
+    if extra is not None:
+        extra = extra.to(torch.int64)
+    return _op('rel_geometry')(pos_src, pos_dst, head_src, head_dst, edge_index, extra)
+
+
+def _rel_geometry_fake(pos_src, pos_dst, head_src, head_dst, edge_index, extra):
+    return pos_src.new_empty((edge_index.size(1), 4 if extra is not None else 3))
+
+
+@_register('rel_geometry', '(Tensor pos_src, Tensor pos_dst, Tensor head_src, Tensor head_dst, Tensor edge_index, Tensor? extra) '
+           '-> Tensor', _rel_geometry_fake)
+def _rel_geometry(pos_src, pos_dst, head_src, head_dst, edge_index, extra):
     dev = pos_src.device
     _require(pos_src, 'pos_src', torch.float32, dev, (None, None))
     _require(pos_dst, 'pos_dst', torch.float32, dev, (None, None))
@@ -382,7 +559,7 @@ def rel_geometry(pos_src: torch.Tensor, pos_dst: torch.Tensor, head_src: torch.T
     return out
 
 
-def pack_mlp_heads(heads) -> torch.Tensor:
+def pack_mlp_heads(heads, mode: Optional[int] = None) -> torch.Tensor:
     """Pack for qcn_mlp_heads_f32 from a list of (w1 [128,128], b1, ln_w, ln_b, w2 [out,128], b2 [out]) tuples."""
     mats, vecs = [], []
     for w1, b1, ln_w, ln_b, w2, b2 in heads:
@@ -395,12 +572,18 @@ def pack_mlp_heads(heads) -> torch.Tensor:
         b2p[:out] = b2
         mats += [w1, w2p]
         vecs += [b1, ln_w, ln_b, b2p]
-    packed, scales = pack_chain_set(mats)
+    packed, scales = pack_chain_set(mats, mode=mode)
     return torch.cat([packed.reshape(-1)] + [v.detach().reshape(-1).float() for v in vecs] + [scale_table(scales)]).contiguous()
 
 
-def mlp_heads(x: torch.Tensor, pack: torch.Tensor, out_dims) -> list:
+def mlp_heads(x: torch.Tensor, pack: torch.Tensor, out_dims, mode: Optional[int] = None) -> list:
     """qcn_mlp_heads_f32: [y_h [n, out_dims[h]]] for up to three MLPLayer heads over the same rows."""
+    return list(_op('mlp_heads')(x, pack, [int(o) for o in out_dims], _mode(mode)))
+
+
+@_register('mlp_heads', '(Tensor x, Tensor pack, int[] out_dims, int mode) -> Tensor[]',
+           lambda x, pack, out_dims, mode: [x.new_empty((x.size(0), int(o))) for o in out_dims])
+def _mlp_heads(x, pack, out_dims, mode):
     dev = x.device
     n, n_heads = x.size(0), len(out_dims)
     _require(x, 'x', torch.float32, dev, (n, C))
@@ -408,16 +591,17 @@ def mlp_heads(x: torch.Tensor, pack: torch.Tensor, out_dims) -> list:
     ys = [torch.empty(n, int(o), dtype=torch.float32, device=dev) for o in out_dims]
     yp = [_ptr(y) for y in ys] + [None] * (3 - n_heads)
     od = (ctypes.c_int * n_heads)(*[int(o) for o in out_dims])
-    _lib.check(_lib.lib().qcn_mlp_heads_f32(_ptr(x), n, _ptr(pack), n_heads, od, yp[0], yp[1], yp[2], _stream(dev)),
+    tok = _prof_begin(PROF_GEMM, float(n) * n_heads * 2 * 2.0 * C * C, dev)
+    _lib.check(_lib.lib().qcn_mlp_heads_f32(_ptr(x), n, _ptr(pack), n_heads, od, yp[0], yp[1], yp[2], int(mode), _stream(dev)),
                'qcn_mlp_heads_f32')
+    _prof_end(tok, dev)
     return ys
 
 
 def pack_gru_whh(weight_hh: torch.Tensor, h0: torch.Tensor, mode: Optional[int] = None) -> torch.Tensor:
     """``nn.GRU.weight_hh_l0`` ([384, 128], gates r, z, n) in the layout qcn_gru_f32 expects for the matmul mode in force
     (include/qcnet_hip.h, K10)."""
-    if mode is None:
-        mode = matmul_mode()
+    mode = _mode(mode)       # bf16: the recurrence has no bf16 form and runs in the split mode (include/qcnet_hip.h)
     w = weight_hh.detach().float()
     if tuple(w.shape) != (3 * C, C):
         raise ValueError('weight_hh must be [384, 128]')
@@ -452,7 +636,7 @@ def pack_gru_whh(weight_hh: torch.Tensor, h0: torch.Tensor, mode: Optional[int] 
 
 
 def gru_last_hidden(x_seq: torch.Tensor, n_steps: int, wih_t: torch.Tensor, b_ih: torch.Tensor, whh_t: torch.Tensor,
-                    b_hh: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
+                    b_hh: torch.Tensor, h0: torch.Tensor, mode: Optional[int] = None) -> torch.Tensor:
     """Final hidden state of a 1-layer GRU(128, 128) over ``n_steps`` steps.  ``x_seq`` [n_seq * n_steps, 128] with
     row = seq * n_steps + t; ``wih_t`` = pack_chain_matrices of the three gate matrices (r, z, n), ``b_ih`` [3, 128]; ``whh_t`` = pack_gru_whh(weight_hh_l0, h0);
     ``b_hh`` [384]; ``h0`` [128].  Input half: one qcn_ln_linear_f32 launch; recurrence: one qcn_gru_f32 launch."""
@@ -460,20 +644,27 @@ def gru_last_hidden(x_seq: torch.Tensor, n_steps: int, wih_t: torch.Tensor, b_ih
     _require(x_seq, 'x_seq', torch.float32, dev, (None, C))
     if x_seq.size(0) % n_steps:
         raise ValueError('x_seq rows (%d) not a multiple of n_steps (%d)' % (x_seq.size(0), n_steps))
-    (gi_r, gi_z, gi_n), _ = ln_linear(x_seq, None, None, wih_t, b_ih)
-    return gru_recurrence(gi_r, gi_z, gi_n, n_steps, whh_t, b_hh, h0)
+    (gi_r, gi_z, gi_n), _ = ln_linear(x_seq, None, None, wih_t, b_ih, mode=mode)
+    return gru_recurrence(gi_r, gi_z, gi_n, n_steps, whh_t, b_hh, h0, mode=mode)
 
 
 def gru_recurrence(gi_r: torch.Tensor, gi_z: torch.Tensor, gi_n: torch.Tensor, n_steps: int, whh_t: torch.Tensor,
-                   b_hh: torch.Tensor, h0: torch.Tensor) -> torch.Tensor:
+                   b_hh: torch.Tensor, h0: torch.Tensor, mode: Optional[int] = None) -> torch.Tensor:
     """qcn_gru_f32 on precomputed input halves gi_* [n_seq * n_steps, 128]."""
+    return _op('gru_recurrence')(gi_r, gi_z, gi_n, int(n_steps), whh_t, b_hh, h0, _mode(mode))
+
+
+@_register('gru_recurrence', '(Tensor gi_r, Tensor gi_z, Tensor gi_n, int n_steps, Tensor whh_t, Tensor b_hh, Tensor h0, int mode) '
+           '-> Tensor', lambda gi_r, gi_z, gi_n, n_steps, whh_t, b_hh, h0, mode: gi_r.new_empty((gi_r.size(0) // n_steps, C)))
+def _gru_recurrence(gi_r, gi_z, gi_n, n_steps, whh_t, b_hh, h0, mode):
     dev = gi_r.device
     if n_steps < 1 or gi_r.size(0) % n_steps:
         raise ValueError('gi rows (%d) not a multiple of n_steps (%d)' % (gi_r.size(0), n_steps))
     n_seq = gi_r.size(0) // n_steps
-    if matmul_mode() == MATMUL_EXACT_F32:
+    if mode == MATMUL_EXACT_F32:
         _require(whh_t, 'whh_t', torch.float32, dev, (C, 3 * C))
     else:
+        mode = MATMUL_SPLIT_F16
         _require(whh_t, 'whh_t', torch.float32, dev, (int(_lib.lib().qcn_gru_pack_floats()),))
     _require(b_hh, 'b_hh', torch.float32, dev, (3 * C,))
     _require(h0, 'h0', torch.float32, dev, (C,))
@@ -481,7 +672,7 @@ def gru_recurrence(gi_r: torch.Tensor, gi_z: torch.Tensor, gi_n: torch.Tensor, n
         _require(t, name, torch.float32, dev, (n_seq * n_steps, C))
     h = torch.empty(n_seq, C, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_gru_f32(_ptr(gi_r), _ptr(gi_z), _ptr(gi_n), _ptr(whh_t), _ptr(b_hh), _ptr(h0), n_seq,
-                                      int(n_steps), _ptr(h), _stream(dev)), 'qcn_gru_f32')
+                                      int(n_steps), _ptr(h), int(mode), _stream(dev)), 'qcn_gru_f32')
     return h
 
 
@@ -496,6 +687,14 @@ def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Te
     ``rowptr`` may be a window (view) of a larger graph's row pointer: its entries index ``col`` / ``eid`` / ``rhat``
     absolutely; ``col_shift`` re-bases the source ids of such a window.  ``row_index`` / ``src_offset`` (int32 [n_dst])
     give every destination its CSR row and a source re-basing of its own, see include/qcnet_hip.h."""
+    return _op('attn_fused')(q, k, v, rhat, rowptr, col, eid, wk, wv, bv, int(rep), int(layout), int(col_shift), row_index,
+                             src_offset)
+
+
+@_register('attn_fused', '(Tensor q, Tensor k, Tensor v, Tensor rhat, Tensor rowptr, Tensor col, Tensor? eid, Tensor wk, Tensor wv, '
+           'Tensor bv, int rep, int layout, int col_shift, Tensor? row_index, Tensor? src_offset) -> Tensor',
+           lambda q, k, v, rhat, rowptr, col, eid, wk, wv, bv, rep, layout, col_shift, row_index, src_offset: torch.empty_like(q))
+def _attn_fused(q, k, v, rhat, rowptr, col, eid, wk, wv, bv, rep, layout, col_shift, row_index, src_offset):
     dev = q.device
     n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
     n_rows = rowptr.numel() - 1
@@ -523,31 +722,63 @@ def attn_fused(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat: torch.Te
     elif n_rows * rep != n_dst or (layout == LAYOUT_PLAIN and rep != 1):
         raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d)' % (n_rows, rep, n_dst))
     out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
+    # algorithmic bytes (r-projection fused): this kernel visits every (edge, mode) pair
+    tok = _prof_begin(PROF_ATTN_FUSED, 1552.0 * num_edges * rep + 1024.0 * n_dst, dev)
     _lib.check(_lib.lib().qcn_attn_fused_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat), _ptr(rowptr), _ptr(col), _ptr(eid),
                                              _ptr(wk), _ptr(wv), _ptr(bv), n_dst, n_src, n_rows, num_edges, int(rep),
                                              int(layout), int(col_shift), _ptr(row_index), _ptr(src_offset), _ptr(out),
                                              _stream(dev)), 'qcn_attn_fused_f32')
+    _prof_end(tok, dev)
     return out
 
 
 # ------------------------------------------------------------------------------------------------
-# profiling hooks for bench.py
+# profiling hooks for bench.py: per-launch event timing on the stream the kernel is launched on (torch's current stream —
+# the one every op of this module launches on).  Python-side state; libqcnet_hip.so itself keeps none.
 # ------------------------------------------------------------------------------------------------
-def prof_enable(on, kinds=None) -> None:
-    """Record hipEvent timings of the given kernel families (``kinds``: iterable of PROF_*; default all)."""
-    mask = 0 if not on else (-1 if kinds is None else sum(1 << int(k) for k in kinds))
-    _lib.check(_lib.lib().qcn_prof_enable(mask), 'qcn_prof_enable')
-
-
 PROF_ATTN, PROF_ATTN_FUSED, PROF_FOURIER, PROF_GEMM = 0, 1, 2, 3
+_PROF_MASK = 0
+_PROF_LOG: list = []
+
+
+def prof_enable(on, kinds=None) -> None:
+    """Record event timings of the given kernel families (``kinds``: iterable of PROF_*; default all).  Each recorded
+    launch costs two event records on its stream, so time only what is reported."""
+    global _PROF_MASK
+    _PROF_MASK = 0 if not on else (~0 if kinds is None else sum(1 << int(k) for k in kinds))
+
+
+def _prof_begin(kind: int, alg_units: float, dev):
+    if not (_PROF_MASK >> kind) & 1:
+        return None
+    start = torch.cuda.Event(enable_timing=True)
+    start.record(torch.cuda.current_stream(dev))
+    return (kind, alg_units, start)
+
+
+def _prof_end(tok, dev) -> None:
+    if tok is None:
+        return
+    stop = torch.cuda.Event(enable_timing=True)
+    stop.record(torch.cuda.current_stream(dev))
+    _PROF_LOG.append(tok + (stop,))
 
 
 def prof_collect(kind: int = -1) -> Tuple[int, float, float]:
-    """(launches, summed kernel ms, summed algorithmic units) of one kernel family, then clears those records."""
-    n, ms, b = ctypes.c_int64(0), ctypes.c_double(0.0), ctypes.c_double(0.0)
-    _lib.check(_lib.lib().qcn_prof_collect(int(kind), ctypes.byref(n), ctypes.byref(ms), ctypes.byref(b)),
-               'qcn_prof_collect')
-    return int(n.value), float(ms.value), float(b.value)
+    """(launches, summed kernel ms, summed algorithmic units) of one kernel family (-1: all), then drops those records.
+    Units: bytes for the attention kernels (2064 E + 1024 n_dst materialised, 1552 E + 1024 n_dst fused,
+    1040 E + 1024 n_dst without positional terms), flop for the MFMA chain kernels."""
+    n, ms, units, rest = 0, 0.0, 0.0, []
+    for rec in _PROF_LOG:
+        if kind >= 0 and rec[0] != kind:
+            rest.append(rec)
+            continue
+        rec[3].synchronize()
+        n += 1
+        ms += rec[2].elapsed_time(rec[3])
+        units += rec[1]
+    _PROF_LOG[:] = rest
+    return n, ms, units
 
 
 RHAT_SPLIT_SCALE_LOG2 = 11      # |rhat| <= sqrt(127): rhat * 2^11 stays inside f16
@@ -555,6 +786,12 @@ RHAT_SPLIT_SCALE_LOG2 = 11      # |rhat| <= sqrt(127): rhat * 2^11 stays inside 
 
 def split_rows(x: torch.Tensor, scale_log2: int = RHAT_SPLIT_SCALE_LOG2) -> torch.Tensor:
     """qcn_split_rows_f16: fp32 rows [N, 128] -> split-f16 rows [N, 256] = [hi | lo] with hi + lo = x * 2^scale_log2."""
+    return _op('split_rows')(x, int(scale_log2))
+
+
+@_register('split_rows', '(Tensor x, int scale_log2) -> Tensor',
+           lambda x, scale_log2: x.new_empty((x.size(0), 2 * C), dtype=torch.float16))
+def _split_rows(x, scale_log2):
     dev = x.device
     _require(x, 'x', torch.float32, dev, (None, C))
     y = torch.empty(x.size(0), 2 * C, dtype=torch.float16, device=dev)
@@ -574,10 +811,17 @@ def _split_scaled(w: torch.Tensor):
     return hi, lo, sw
 
 
-def pack_attn_modes(wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
-    """Weight pack of qcn_attn_modes_f32 (include/qcnet_hip.h): per head the MFMA fragments of wk / wv (the
-    positional projections with the LN_r scale folded in, [128 out, 128 in]) as split f16, then the two fp32
-    factors that undo the weight and rhat scaling."""
+def pack_attn_modes(wk: torch.Tensor, wv: torch.Tensor, mode: Optional[int] = None) -> torch.Tensor:
+    """Weight pack of qcn_attn_modes_f32 / qcn_attn_modes_bf16 (include/qcnet_hip.h): per head the MFMA fragments of wk /
+    wv (the positional projections with the LN_r scale folded in, [128 out, 128 in]).  Split mode (also used by the exact
+    mode): hi / lo f16 planes, then the two fp32 factors that undo the weight and rhat scaling.  bf16 mode: one bf16 plane
+    (round to nearest even), no scaling."""
+    if _mode(mode) == MATMUL_BF16:
+        frags = [w.detach().float().bfloat16().view(8, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).reshape(8, 4, 64, 8)
+                 for w in (wk, wv)]                                         # [head, ks, lane, 8]
+        pack = torch.stack(frags, dim=1).contiguous().view(torch.uint8).reshape(-1)   # [head, mat, ks, lane, 8]
+        assert pack.numel() == _lib.lib().qcn_attn_modes_bf16_pack_bytes()
+        return pack
     frags, scales = [], []
     for w in (wk, wv):
         hi, lo, sw = _split_scaled(w)
@@ -591,33 +835,58 @@ def pack_attn_modes(wk: torch.Tensor, wv: torch.Tensor) -> torch.Tensor:
     return pack
 
 
-def attn_modes(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat_split: torch.Tensor, rowptr: torch.Tensor,
+def attn_modes(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat_op: torch.Tensor, rowptr: torch.Tensor,
                col: torch.Tensor, eid: Optional[torch.Tensor], wpack: torch.Tensor, bv: torch.Tensor,
                rep: int, layout: int, col_shift: int = 0) -> torch.Tensor:
-    """qcn_attn_modes_f32: attention propagate of a mode-replicated relation (rep <= 6 queries per CSR row share its
-    edges) on the matrix cores; same result as attn_fused on the same graph."""
+    """qcn_attn_modes_f32 / qcn_attn_modes_bf16: attention propagate of a mode-replicated relation (rep <= 6 queries per CSR
+    row share its edges) on the matrix cores; same result as attn_fused on the same graph (bf16: with the positional
+    projections' operands rounded to bf16).  ``rhat_op``: split-f16 rows [., 256] (float16) with the split pack, or bf16
+    rows [., 128] (bfloat16) with the bf16 pack."""
+    return _op('attn_modes')(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, int(rep), int(layout), int(col_shift))
+
+
+@_register('attn_modes', '(Tensor q, Tensor k, Tensor v, Tensor rhat_op, Tensor rowptr, Tensor col, Tensor? eid, Tensor wpack, '
+           'Tensor bv, int rep, int layout, int col_shift) -> Tensor',
+           lambda q, k, v, rhat_op, rowptr, col, eid, wpack, bv, rep, layout, col_shift: torch.empty_like(q))
+def _attn_modes(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, rep, layout, col_shift):
     dev = q.device
+    lib = _lib.lib()
     n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
     n_rows = rowptr.numel() - 1
+    bf16 = rhat_op.dtype == torch.bfloat16
     _require(q, 'q', torch.float32, dev, (n_dst, C))
     _require(k, 'k', torch.float32, dev, (n_src, C))
     _require(v, 'v', torch.float32, dev, (n_src, C))
-    _require(rhat_split, 'rhat_split', torch.float16, dev, (None if eid is not None else num_edges, 2 * C))
+    n_feat = None if eid is not None else num_edges
+    if bf16:
+        _require(rhat_op, 'rhat_bf16', torch.bfloat16, dev, (n_feat, C))
+        _require(wpack, 'wpack', torch.uint8, dev, (lib.qcn_attn_modes_bf16_pack_bytes(),))
+    else:
+        _require(rhat_op, 'rhat_split', torch.float16, dev, (n_feat, 2 * C))
+        _require(wpack, 'wpack', torch.uint8, dev, (lib.qcn_attn_modes_pack_bytes(),))
     _require(rowptr, 'rowptr', torch.int32, dev, (n_rows + 1,))
     _require(col, 'col', torch.int32, dev, (num_edges,))
     if eid is not None:
         _require(eid, 'eid', torch.int32, dev, (num_edges,))
-    _require(wpack, 'wpack', torch.uint8, dev, (_lib.lib().qcn_attn_modes_pack_bytes(),))
     _require(bv, 'bv', torch.float32, dev, (C,))
     if n_rows * rep != n_dst or layout not in (LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR):
         raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d) or plain layout' % (n_rows, rep, n_dst))
     out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
-    _lib.check(_lib.lib().qcn_attn_modes_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat_split), _ptr(rowptr), _ptr(col),
-                                             _ptr(eid), _ptr(wpack), _ptr(bv), n_dst, n_src, n_rows, num_edges,
-                                             rhat_split.size(0), int(rep), int(layout), int(col_shift), _ptr(out),
-                                             _stream(dev)),
-               'qcn_attn_modes_f32')
+    fn, name = (lib.qcn_attn_modes_bf16, 'qcn_attn_modes_bf16') if bf16 else (lib.qcn_attn_modes_f32, 'qcn_attn_modes_f32')
+    # algorithmic bytes: every base edge is processed once for all rep modes (rhat row + k row + v row + indices); the bf16
+    # form reads a 256-byte rhat row (1296 E + 1024 n_dst)
+    tok = _prof_begin(PROF_ATTN_FUSED, (1296.0 if bf16 else 1552.0) * num_edges + 1024.0 * n_dst, dev)
+    _lib.check(fn(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat_op), _ptr(rowptr), _ptr(col), _ptr(eid), _ptr(wpack), _ptr(bv), n_dst,
+                  n_src, n_rows, num_edges, rhat_op.size(0), int(rep), int(layout), int(col_shift), _ptr(out), _stream(dev)),
+               name)
+    _prof_end(tok, dev)
     return out
+
+
+def attn_modes_supported(n_dst: int, n_src: int, n_feat_rows: int) -> bool:
+    """qcn_attn_modes_* address rows by 32-bit byte offsets: every row count must stay below 2^23 (beyond that
+    AttentionLayer falls back to qcn_attn_fused_f32, which handles the same graph)."""
+    return max(int(n_dst), int(n_src), int(n_feat_rows)) < (1 << 23)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -648,9 +917,23 @@ def motion_metrics(pred: torch.Tensor, target: torch.Tensor, prob: Optional[torc
                    keep_invalid_final_step: bool = True, miss_threshold: float = 2.0) -> torch.Tensor:
     """qcn_motion_metrics_f32: per-sample records [n, 16] (columns: METRIC_COLUMNS) of every metric class's state update.
     pred [n, K, T, Dp], target [n, T, Dt], prob [n, K], valid_mask [n, T], select [n]."""
-    dev = pred.device
     if pred.dim() != 4 or target.dim() != 3:
         raise ValueError('pred must be [n, modes, steps, dim] and target [n, steps, dim]')
+    dp, dt = pred.size(3), target.size(2)
+    if pos_dim is None:
+        pos_dim = dp if pred_head < 0 else dp - 1
+    if target_head < 0:
+        target_head = dt + target_head
+    return _op('motion_metrics')(pred, target, prob, valid_mask, select, int(pos_dim), int(pred_head), int(target_head),
+                                 int(max_guesses), bool(keep_invalid_final_step), float(miss_threshold))
+
+
+@_register('motion_metrics', '(Tensor pred, Tensor target, Tensor? prob, Tensor? valid_mask, Tensor? select, int pos_dim, '
+           'int pred_head, int target_head, int max_guesses, bool keep_invalid_final_step, float miss_threshold) -> Tensor',
+           lambda pred, *a: pred.new_empty((pred.size(0), 16)))
+def _motion_metrics(pred, target, prob, valid_mask, select, pos_dim, pred_head, target_head, max_guesses,
+                    keep_invalid_final_step, miss_threshold):
+    dev = pred.device
     n, k, t, dp = pred.shape
     dt = target.size(2)
     pred = pred.contiguous()
@@ -662,10 +945,6 @@ def motion_metrics(pred: torch.Tensor, target: torch.Tensor, prob: Optional[torc
         _require(prob, 'prob', torch.float32, dev, (n, k))
     valid_mask = _as_u8(valid_mask, 'valid_mask', dev, (n, t))
     select = _as_u8(select, 'select', dev, (n,))
-    if pos_dim is None:
-        pos_dim = dp if pred_head < 0 else dp - 1
-    if target_head < 0:
-        target_head = dt + target_head
     record = torch.empty(n, METRIC_RECORD, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_motion_metrics_f32(_ptr(pred), dp, _ptr(prob), _ptr(target), dt, _ptr(valid_mask), _ptr(select), n, k,
                                                  t, int(pos_dim), int(pred_head), int(target_head), int(max_guesses),
@@ -678,12 +957,18 @@ def to_agent_frame(position: torch.Tensor, heading: torch.Tensor, origin_step: i
                    n_steps: Optional[int] = None) -> torch.Tensor:
     """qcn_to_agent_frame_f32: [A, n_steps, 4] targets (x, y, z, heading) in the frame of each agent's pose at
     ``origin_step`` (predictors/temp_ens_learn_agg.py:104-121)."""
+    if n_steps is None:
+        n_steps = position.size(1) - first_step
+    return _op('to_agent_frame')(position, heading, int(origin_step), int(first_step), int(n_steps))
+
+
+@_register('to_agent_frame', '(Tensor position, Tensor heading, int origin_step, int first_step, int n_steps) -> Tensor',
+           lambda position, heading, origin_step, first_step, n_steps: position.new_empty((position.size(0), n_steps, 4)))
+def _to_agent_frame(position, heading, origin_step, first_step, n_steps):
     dev = position.device
     a, total, pd = position.shape
     _require(position, 'position', torch.float32, dev, (a, total, pd))
     _require(heading, 'heading', torch.float32, dev, (a, total))
-    if n_steps is None:
-        n_steps = total - first_step
     out = torch.empty(a, n_steps, 4, dtype=torch.float32, device=dev)
     _lib.check(_lib.lib().qcn_to_agent_frame_f32(_ptr(position), _ptr(heading), a, total, pd, int(origin_step), int(first_step),
                                                  int(n_steps), _ptr(out), _stream(dev)), 'qcn_to_agent_frame_f32')
@@ -694,6 +979,17 @@ def to_world_frame(traj: torch.Tensor, position: torch.Tensor, heading: torch.Te
                    rows: Optional[torch.Tensor] = None) -> torch.Tensor:
     """qcn_to_world_frame_f32: [n_rows, K, T, 2] world-frame trajectories of the agents ``rows`` (all agents when None) from
     agent-frame ``traj`` [A, K, T, D] (predictors/qcnet_sliding.py:179-192)."""
+    return _op('to_world_frame')(traj, position, heading, int(origin_step), rows)
+
+
+def _to_world_frame_fake(traj, position, heading, origin_step, rows):
+    n = traj.size(0) if rows is None else rows.numel()
+    return traj.new_empty((n, traj.size(1), traj.size(2), 2))
+
+
+@_register('to_world_frame', '(Tensor traj, Tensor position, Tensor heading, int origin_step, Tensor? rows) -> Tensor',
+           _to_world_frame_fake)
+def _to_world_frame(traj, position, heading, origin_step, rows):
     dev = traj.device
     a, k, t, d = traj.shape
     traj = traj.contiguous()
@@ -717,6 +1013,18 @@ def nms_select(traj: torch.Tensor, conf: torch.Tensor, gt: torch.Tensor, cand_pe
                radius: float = 2.5, miss_threshold: float = 2.0) -> Tuple[torch.Tensor, torch.Tensor]:
     """qcn_nms_select_f32: traj [n, M, T, 2], conf [n, M], gt [n, T, 2] -> (selected [n, W, n_select] int32,
     score [n, W, 3] = min FDE / min ADE / miss) for the window sizes 1..W = M // cand_per_window (utils/nms.py:11-38)."""
+    sel, score = _op('nms_select')(traj, conf, gt, int(cand_per_window), int(n_select), float(radius), float(miss_threshold))
+    return sel, score
+
+
+def _nms_select_fake(traj, conf, gt, cand_per_window, n_select, radius, miss_threshold):
+    n, w = traj.size(0), traj.size(1) // cand_per_window
+    return traj.new_empty((n, w, n_select), dtype=torch.int32), traj.new_empty((n, w, 3))
+
+
+@_register('nms_select', '(Tensor traj, Tensor conf, Tensor gt, int cand_per_window, int n_select, float radius, '
+           'float miss_threshold) -> (Tensor, Tensor)', _nms_select_fake)
+def _nms_select(traj, conf, gt, cand_per_window, n_select, radius, miss_threshold):
     dev = traj.device
     n, m, t, _ = traj.shape
     traj, conf, gt = traj.contiguous(), conf.contiguous(), gt.contiguous()
@@ -745,6 +1053,19 @@ def mask_pairs(mask_src: torch.Tensor, mask_dst: torch.Tensor, delta_lo: Optiona
     """qcn_mask_pairs_count / _fill: the edges (b * n + i, b * m + j) with mask_src[b, i] & mask_dst[b, j] (and
     delta_lo <= j - i <= delta_hi when a band is given) in row-major order — dense_to_sparse of the outer-product adjacency
     without materialising it.  Returns ``(edge_index [2, E] int64, offset [B * n + 1] int64)``; one host synchronisation."""
+    lo = _NO_BAND[0] if delta_lo is None else int(delta_lo)
+    hi = _NO_BAND[1] if delta_hi is None else int(delta_hi)
+    ei, off = _op('mask_pairs')(mask_src, mask_dst, lo, hi)
+    return ei, off
+
+
+def _mask_pairs_fake(mask_src, mask_dst, lo, hi):
+    return (mask_src.new_empty((2, _dyn()), dtype=torch.int64),
+            mask_src.new_empty((mask_src.size(0) * mask_src.size(1) + 1,), dtype=torch.int64))
+
+
+@_register('mask_pairs', '(Tensor mask_src, Tensor mask_dst, int delta_lo, int delta_hi) -> (Tensor, Tensor)', _mask_pairs_fake)
+def _mask_pairs(mask_src, mask_dst, lo, hi):
     dev = mask_src.device
     if mask_src.dim() != 2 or mask_dst.dim() != 2 or mask_src.size(0) != mask_dst.size(0):
         raise ValueError('masks must be [B, n] and [B, m]')
@@ -752,8 +1073,6 @@ def mask_pairs(mask_src: torch.Tensor, mask_dst: torch.Tensor, delta_lo: Optiona
     m = mask_dst.size(1)
     ms = _as_u8(mask_src, 'mask_src', dev, (b, n))
     md = _as_u8(mask_dst, 'mask_dst', dev, (b, m))
-    lo = _NO_BAND[0] if delta_lo is None else int(delta_lo)
-    hi = _NO_BAND[1] if delta_hi is None else int(delta_hi)
     lib = _lib.lib()
     st = _stream(dev)
     rows = b * n
@@ -774,6 +1093,17 @@ def mask_pairs(mask_src: torch.Tensor, mask_dst: torch.Tensor, delta_lo: Optiona
 def coalesce_max(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], num_nodes: int
                  ) -> Tuple[torch.Tensor, Optional[torch.Tensor]]:
     """qcn_coalesce_count / _fill: edges sorted by (src, dst), duplicates merged with the largest uint8 attribute."""
+    out = _op('coalesce_max')(edge_index, edge_attr, int(num_nodes))
+    return out[0], (out[1] if edge_attr is not None else None)
+
+
+def _coalesce_fake(edge_index, edge_attr, num_nodes):
+    n = _dyn()
+    return [edge_index.new_empty((2, n))] + ([edge_attr.new_empty((n,))] if edge_attr is not None else [])
+
+
+@_register('coalesce_max', '(Tensor edge_index, Tensor? edge_attr, int num_nodes) -> Tensor[]', _coalesce_fake)
+def _coalesce_max(edge_index, edge_attr, num_nodes):
     dev = edge_index.device
     if edge_index.dim() != 2 or edge_index.size(0) != 2:
         raise ValueError('edge_index must be [2, E]')
@@ -798,4 +1128,4 @@ def coalesce_max(edge_index: torch.Tensor, edge_attr: Optional[torch.Tensor], nu
     if e:
         _lib.check(lib.qcn_coalesce_fill(_ptr(ws), _ptr(offset), e, int(num_nodes), _ptr(out_index[0]), _ptr(out_index[1]),
                                          _ptr(out_attr), st), 'qcn_coalesce_fill')
-    return out_index, out_attr
+    return [out_index] + ([out_attr] if out_attr is not None else [])

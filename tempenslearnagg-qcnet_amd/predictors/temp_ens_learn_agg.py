@@ -93,7 +93,7 @@ class TempEnsLearnAgg(nn.Module):
         enc, dec = self.base_model.encoder, self.base_model.decoder
         A = int(data['agent']['num_nodes'])
         dev = data['agent']['position'].device
-        inputs_ready(dev, data)                 # the preparation stream (utils/prep.py) may read `data` from here on
+        inputs_ready(dev, data, self)           # the preparation stream (utils/prep.py) may read `data` from here on
         map_enc = enc.map_encoder(data)
         cache = enc.agent_encoder.precompute(data, 1, n_f)
         # the frame batch replicates the map per frame; the decoder folds the polygon sources onto this one copy
@@ -117,7 +117,7 @@ class TempEnsLearnAgg(nn.Module):
         """Ten sliding QCNet frames + learned aggregation (reference :196-221, :261)."""
         if self.batch_frames and self.share_map_encoding and self.share_frame_work:
             return self._predict_frames_batched(data)
-        inputs_ready(data['agent']['position'].device, data)
+        inputs_ready(data['agent']['position'].device, data, self)
         map_enc = self.base_model.encoder.map_encoder(data) if self.share_map_encoding else None
         agent_cache = None
         if self.share_frame_work:

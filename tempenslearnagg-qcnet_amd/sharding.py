@@ -14,7 +14,10 @@ import torch.distributed as dist
 
 RECORD_MODES = 6
 RECORD_STEPS = 50
-RECORD_WIDTH = 1 + RECORD_MODES * RECORD_STEPS * 2 + RECORD_MODES   # scenario id, trajectories, probabilities
+# scenario id, trajectories, probabilities of the AV2 configuration; records of another configuration have the width their
+# predictions give (focal_records) and gather_records agrees on it across ranks
+RECORD_WIDTH = 1 + RECORD_MODES * RECORD_STEPS * 2 + RECORD_MODES
+MAX_SCENARIO_ID = 1 << 24    # ids travel as an fp32 column of the record: exact below 2^24
 
 
 def shard_scenario_ids(num_scenarios: int, rank: int, world_size: int) -> List[int]:
@@ -31,6 +34,10 @@ def focal_index(scenario_ids: Sequence[int], data) -> Tuple[torch.Tensor, torch.
     the preparation stream: the host then never waits for the prediction kernels of the main stream and can enqueue the
     next batch while this one runs."""
     from .utils.prep import run_prep
+
+    if len(scenario_ids) and not 0 <= min(scenario_ids) <= max(scenario_ids) < MAX_SCENARIO_ID:
+        raise ValueError('scenario ids must be dense integers in [0, 2^24): they are carried as an fp32 record column '
+                         '(map dataset ids such as AV2 UUID strings to indices first)')
 
     def make():
         category = data['agent']['category']
@@ -96,21 +103,31 @@ def validation_metric_sums(data, pred: Dict[str, torch.Tensor], num_historical_s
 
 
 def gather_records(records: torch.Tensor, world_size: int) -> torch.Tensor:
-    """all_gather of per-scenario records from every rank (ragged counts padded to the max), sorted by id."""
+    """all_gather of per-scenario records from every rank (ragged counts padded to the max), sorted by id.  A rank whose
+    shard is empty passes a [0, anything] tensor: the record width is agreed on across ranks (the maximum; ranks with
+    records must agree with each other)."""
     if world_size == 1 or not dist.is_initialized():
         out = records
     else:
-        count = torch.tensor([records.size(0)], dtype=torch.int64, device=records.device)
-        counts = [torch.zeros_like(count) for _ in range(world_size)]
-        dist.all_gather(counts, count)
-        cap = int(max(int(c) for c in counts))
-        padded = records.new_full((cap, records.size(1)), -1.0)
-        padded[:records.size(0)] = records
-        gathered = records.new_empty((world_size * cap, records.size(1)))
-        dist.all_gather_into_tensor(gathered, padded)
-        keep = torch.cat([torch.arange(cap, device=records.device) < int(c) for c in counts])
+        shape = torch.tensor([records.size(0), records.size(1) if records.size(0) else 0], dtype=torch.int64,
+                             device=records.device)
+        shapes = [torch.zeros_like(shape) for _ in range(world_size)]
+        dist.all_gather(shapes, shape)
+        shapes = [[int(v) for v in t.tolist()] for t in shapes]
+        counts = [c for c, _ in shapes]
+        width = max(w for _, w in shapes)
+        if any(c and w != width for c, w in shapes):
+            raise ValueError('ranks disagree on the record width: %s' % (shapes,))
+        cap = max(counts)
+        padded = records.new_full((cap, width), -1.0)
+        if records.size(0):
+            padded[:records.size(0)] = records
+        gathered = records.new_empty((world_size * cap, width))
+        if cap * width:
+            dist.all_gather_into_tensor(gathered, padded)
+        keep = torch.cat([torch.arange(cap, device=records.device) < c for c in counts])
         out = gathered[keep]
-    return out[torch.argsort(out[:, 0])]
+    return out[torch.argsort(out[:, 0])] if out.size(0) else out
 
 
 def reduce_metric_sums(sums: torch.Tensor, world_size: int) -> torch.Tensor:
@@ -119,12 +136,20 @@ def reduce_metric_sums(sums: torch.Tensor, world_size: int) -> torch.Tensor:
     return sums
 
 
+endpoint_metric_sums.width = 6
+validation_metric_sums.width = 2 * len(VALIDATION_METRICS)
+
+
 def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], object], num_scenarios: int,
                 batch_size: int, rank: int, world_size: int, device,
-                metric_fn: Callable = endpoint_metric_sums) -> Tuple[torch.Tensor, torch.Tensor]:
+                metric_fn: Callable = endpoint_metric_sums, metric_width: int = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Runs this rank's shard and returns (all records sorted by scenario id, reduced metric sums).  ``metric_fn(data, pred)``
     returns the batch's (sum, count) pairs: ``validation_metric_sums`` on the GPU (the reference's seven metrics from the
-    HIP kernel); the default is device-agnostic torch arithmetic so the collectives can be exercised over gloo."""
+    HIP kernel); the default is device-agnostic torch arithmetic so the collectives can be exercised over gloo.
+    ``metric_width``: length of that vector (default: ``metric_fn.width``) — a rank whose shard is empty
+    (num_scenarios < world_size) contributes zeros of the SAME length to the closing all_reduce."""
+    if metric_width is None:
+        metric_width = getattr(metric_fn, 'width', None)
     records = []
     sums = None
     for ids in batches(shard_scenario_ids(num_scenarios, rank, world_size), batch_size):
@@ -132,8 +157,13 @@ def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], objec
         pred = predict_fn(data)
         records.append(focal_records(ids, data, pred))
         part = metric_fn(data, pred).float()
+        if metric_width is not None and part.numel() != metric_width:
+            raise ValueError('metric_fn returned %d values, metric_width says %d' % (part.numel(), metric_width))
         sums = part if sums is None else sums + part
     if sums is None:
-        sums = torch.zeros(6, device=device)
-    records = torch.cat(records) if records else torch.empty(0, RECORD_WIDTH, device=device)
+        if metric_width is None:
+            raise ValueError('this rank has no scenarios and the width of metric_fn\'s result is unknown: pass metric_width '
+                             '(every rank must all_reduce a vector of the same length)')
+        sums = torch.zeros(metric_width, device=device)
+    records = torch.cat(records) if records else torch.empty(0, 0, device=device)
     return gather_records(records, world_size), reduce_metric_sums(sums, world_size)

@@ -59,15 +59,32 @@ def _record(obj, stream, seen) -> None:
                 _record(v, stream, seen)
 
 
-def inputs_ready(device: torch.device, data=None) -> None:
+def _parameter_versions(module) -> tuple:
+    return tuple((p.data_ptr(), p._version) for p in module.parameters()) + \
+        tuple((b.data_ptr(), b._version) for b in module.buffers())
+
+
+def inputs_ready(device: torch.device, data=None, module=None) -> None:
     """Order the side stream after the inputs (call once where fresh inputs enter, e.g. at the top of ``predict``):
-    sections started later may read them.  A container that carries a ready mark (``data.mark_ready()``, recorded by
-    ``data.to(device)``) is waited for by its event alone, so the preparation of this batch may overlap whatever the main
-    stream still runs for the previous one; without the mark the side stream waits for everything enqueued on the
-    current stream so far."""
+    sections started later may read them.  The side stream waits for the container's ready mark ALONE
+    (``data.mark_ready()``, recorded by ``data.to(device)``) — so that the preparation of this batch may overlap
+    whatever the main stream still runs for the previous one — only when nothing it reads can still be in flight on the
+    main stream: the mark still describes the inputs (``data.ready_event()``: no store entry replaced, no tensor
+    written in place since) AND the parameters / buffers of ``module`` (the sections read Fourier weights and type
+    embeddings on the side stream) are the ones the previous call saw, i.e. no ``load_state_dict`` / ``model.to`` /
+    in-place update since.  In every other case the side stream waits for everything enqueued on the current stream."""
     if ENABLED and device.type == 'cuda':
-        event = getattr(data, '_ready_event', None) if data is not None else None
-        if event is not None and os.environ.get('QCN_PREP_WAIT_MAIN', '0') == '0':
+        event = None
+        if data is not None and os.environ.get('QCN_PREP_WAIT_MAIN', '0') == '0':
+            event = data.ready_event() if hasattr(data, 'ready_event') else None
+        if event is not None and module is not None:
+            versions = _parameter_versions(module)
+            if module.__dict__.get('_prep_parameter_versions') != versions:
+                module.__dict__['_prep_parameter_versions'] = versions
+                event = None        # weights changed (or first call): their writes may still be queued on the main stream
+        elif module is not None:
+            module.__dict__['_prep_parameter_versions'] = _parameter_versions(module)
+        if event is not None:
             side_stream(device).wait_event(event)
         else:
             side_stream(device).wait_stream(torch.cuda.current_stream(device))

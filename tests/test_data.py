@@ -109,3 +109,38 @@ def test_ready_mark_and_derived_cache_follow_the_container():
     assert sharding.focal_index([0, 1], batch)[0] is focal          # once per container
     batch['agent'] = dict(batch['agent'])                # a replaced store is new input
     assert '_derived' not in batch.__dict__
+
+
+def test_store_changes_drop_the_derived_cache_and_ready_mark():
+    """`data['agent']['x'] = t` (the raw inner store), an in-place write or a delete must invalidate what was
+    derived from the inputs (focal rows) and the ready mark of the preparation stream."""
+    from tempenslearnagg_qcnet_amd import sharding
+    from tempenslearnagg_qcnet_amd.synthetic import SCENE_TINY, make_batch
+    data = make_batch([0, 1], **SCENE_TINY)
+    calls = []
+    fn = lambda: calls.append(1) or len(calls)
+    assert data.derived('k', fn) == 1 and data.derived('k', fn) == 1
+    data['agent']['category'] = data['agent']['category'].clone()          # replaced entry
+    assert data.derived('k', fn) == 2
+    data['agent']['category'].add_(0)                                      # in-place write (version counter moves)
+    assert data.derived('k', fn) == 3
+    assert data.derived('k', fn) == 3
+    # a marker standing in for the CUDA event: dropped by every kind of change
+    for change in (lambda: data['agent'].__setitem__('extra', torch.zeros(1)), lambda: data['agent'].pop('extra'),
+                   lambda: data['agent']['heading'].mul_(1.0), lambda: data.__setitem__('foo', {'a': torch.zeros(1)})):
+        data._ready_event, data._ready_versions = 'mark', data._tensor_versions()
+        assert data.ready_event() == 'mark'
+        change()
+        assert data.ready_event() is None
+    # the focal rows follow a rewritten category tensor (the cache used to be keyed by the scenario ids alone)
+    rows0, _ = sharding.focal_index([0, 1], data)
+    cat = data['agent']['category']
+    new = cat.clone()
+    new[rows0] = 0
+    other = [i for i in range(cat.numel()) if i not in rows0.tolist()]
+    b = data['agent']['batch']
+    pick = [next(i for i in other if int(b[i]) == g) for g in (0, 1)]
+    new[pick] = 3
+    cat.copy_(new)
+    rows1, _ = sharding.focal_index([0, 1], data)
+    assert rows1.tolist() == pick

@@ -251,12 +251,48 @@ def test_back_to_back_batches_overlap_without_changing_predictions():
         fresh = make_batch(id_sets[0], **cfg['scene']).to(DEV)
         for name in ('position', 'heading', 'velocity', 'valid_mask', 'predict_mask'):
             fresh['agent'][name] = batches[1]['agent'][name].clone()
-        assert getattr(fresh, '_ready_event', None) is not None     # store entries may be replaced; stores may not
+        assert fresh.ready_event() is None                          # a replaced store entry drops the mark
         fresh.mark_ready()
         want = model.predict(fresh)
         torch.cuda.synchronize()
         for k in keys:
             assert torch.equal(moved[k], want[k]), k
+        # the same rewrites WITHOUT mark_ready, queued on the main stream behind a long-running prediction, must
+        # not be overtaken by the preparation stream (the mark is void once a tensor's version counter moved) ...
+        b2 = batches[2]
+        assert b2.ready_event() is not None
+        model.predict(batches[1])                                   # keeps the main stream busy while the writes queue
+        for name in ('position', 'heading', 'velocity', 'valid_mask', 'predict_mask'):
+            b2['agent'][name].copy_(batches[1]['agent'][name])
+        assert b2.ready_event() is None
+        moved2 = model.predict(b2)
+        # ... and neither may a weight update queued there (load_state_dict right before predict)
+        sd_old = {k: v.clone() for k, v in model.state_dict().items()}
+        sd_new = {k: v.clone() for k, v in sd_old.items()}
+        for k in sd_new:
+            if k.endswith('freqs.weight') or 'type_a_emb' in k or 'type_pl_emb' in k:
+                sd_new[k] = sd_new[k] * 1.25
+        model.predict(batches[1])
+        model.load_state_dict(sd_new)
+        after_load = model.predict(fresh)
+        torch.cuda.synchronize()
+        from tempenslearnagg_qcnet_amd.utils import prep
+        try:
+            prep.ENABLED = False
+            inline = model.predict(fresh)
+        finally:
+            prep.ENABLED = True
+        torch.cuda.synchronize()
+        model.load_state_dict(sd_old)
+        fresh2 = make_batch(id_sets[2], **cfg['scene']).to(DEV)
+        for name in ('position', 'heading', 'velocity', 'valid_mask', 'predict_mask'):
+            fresh2['agent'][name] = batches[1]['agent'][name].clone()
+        want2 = model.predict(fresh2)
+        torch.cuda.synchronize()
+        for k in keys:
+            assert torch.equal(moved2[k], want2[k]), k
+            assert torch.equal(after_load[k], inline[k]), k
+            assert not torch.equal(after_load[k], want[k]), k        # the new weights were really used
 
 
 def test_ragged_batch_with_dead_agents_vs_oracle():

@@ -23,12 +23,22 @@ def _fake_predict(data):
     return {'traj_refine': torch.cat([traj, torch.ones_like(traj)], dim=-1), 'pi_softmax': torch.softmax(pi, -1)}
 
 
-def _worker(rank, world, port, num_scenarios, out_dir):
+def _wide_metric(data, pred):
+    """A 14-value (sum, count) vector like sharding.validation_metric_sums (which needs the GPU)."""
+    base = sharding.endpoint_metric_sums(data, pred)
+    return torch.cat([base, base, base[:2]])
+
+
+_wide_metric.width = 14
+
+
+def _worker(rank, world, port, num_scenarios, out_dir, wide=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
+    kw = {'metric_fn': _wide_metric} if wide else {}
     recs, sums = sharding.run_sharded(_fake_predict, lambda ids: make_batch(ids, **SCENE_TINY), num_scenarios, 3,
-                                      rank, world, torch.device('cpu'))
+                                      rank, world, torch.device('cpu'), **kw)
     torch.save({'records': recs, 'sums': sums}, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -52,6 +62,37 @@ def test_sharded_run_equals_single_process(tmp_path):
         assert torch.equal(got['records'], single_recs)                   # bit-identical to the 1-process run
         assert torch.allclose(got['sums'], single_sums, rtol=1e-6)
         assert got['sums'][1] == num_scenarios
+
+
+def test_empty_shard_with_a_wide_metric_vector(tmp_path):
+    """num_scenarios < world_size: rank 1 has nothing to run and must still join both collectives with tensors of the
+    other rank's widths (14 metric values, the record width the predictions give)."""
+    num_scenarios, world = 1, 2
+    mp.spawn(_worker, args=(world, _free_port(), num_scenarios, str(tmp_path), True), nprocs=world, join=True)
+    single_recs, single_sums = sharding.run_sharded(_fake_predict, lambda ids: make_batch(ids, **SCENE_TINY),
+                                                    num_scenarios, 3, 0, 1, torch.device('cpu'), metric_fn=_wide_metric)
+    assert single_sums.numel() == 14
+    for r in range(world):
+        got = torch.load(os.path.join(str(tmp_path), 'rank%d.pt' % r))
+        assert torch.equal(got['records'], single_recs)
+        assert torch.allclose(got['sums'], single_sums, rtol=1e-6)
+
+
+def test_empty_shard_needs_a_known_metric_width():
+    import pytest
+    with pytest.raises(ValueError, match='metric_width'):
+        sharding.run_sharded(_fake_predict, lambda ids: make_batch(ids, **SCENE_TINY), 0, 3, 0, 1, torch.device('cpu'),
+                             metric_fn=lambda d, p: torch.zeros(3))
+    recs, sums = sharding.run_sharded(_fake_predict, lambda ids: make_batch(ids, **SCENE_TINY), 0, 3, 0, 1,
+                                      torch.device('cpu'))
+    assert recs.size(0) == 0 and sums.tolist() == [0.0] * 6
+
+
+def test_scenario_ids_must_fit_the_fp32_column():
+    import pytest
+    data = make_batch([0], **SCENE_TINY)
+    with pytest.raises(ValueError, match='2\\^24'):
+        sharding.focal_index([1 << 24], data)
 
 
 def test_partition_is_a_disjoint_cover():
