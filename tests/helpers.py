@@ -89,5 +89,40 @@ def rel_err(got: torch.Tensor, want: torch.Tensor) -> float:
     return float((got - want).abs().max()) / max(denom, 1e-12) if want.numel() else 0.0
 
 
+ATOL_SCALE = 2e-6          # predictions (trajectories, scales, logits, probabilities)
+ATOL_SCALE_HIDDEN = 5e-6   # 128-wide hidden states (x_a, x_pl, m, final_m): see assert_close
+HIDDEN_KEYS = ('m', 'final_m', 'x_a', 'x_pl')
+
+
+def assert_close(got: torch.Tensor, want: torch.Tensor, name: str = '', rtol: float = 1e-4, atol: float = None) -> float:
+    """Per-element parity bar of the model-level tests:  |got - want| <= rtol |want| + atol  for EVERY
+    element, rtol = 1e-4 (BASELINE.json: "within 1e-4 relative").  ``atol`` is the absolute floor for elements near zero;
+    default ATOL_SCALE * max|want| = 2e-6 of the tensor's scale — fp32 dot products over 128 terms of that scale carry an
+    absolute rounding error of about that size whatever the size of their result, so a purely relative bound on an element
+    that happens to cancel to ~0 is not meaningful.  (The old bar, max|got - want| / max|want| < 1e-4, is 50x looser on
+    such elements.)  Finding of round 2 (full-size runs): every prediction tensor sits at <= 0.65 of this bar; the hidden
+    mode embeddings ``m`` (outputs of 28 stacked attention layers + the GRU, |m| up to ~10) have elements near zero whose
+    absolute error reaches 3.4e-5 = 4e-6 of the tensor's scale (max-norm error 4e-6 .. 7e-6), so hidden states
+    (``HIDDEN_KEYS``) get the floor ATOL_SCALE_HIDDEN = 5e-6 of their scale.
+    Returns the worst ratio |got - want| / (rtol |want| + atol)."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape, (name, tuple(got.shape), tuple(want.shape))
+    if want.numel() == 0:
+        return 0.0
+    assert bool(torch.isfinite(got).all()), name
+    if atol is None:
+        atol = (ATOL_SCALE_HIDDEN if name in HIDDEN_KEYS else ATOL_SCALE) * float(want.abs().max())
+    bound = rtol * want.abs() + atol
+    ratio = (got - want).abs() / bound.clamp_min(1e-300)
+    worst = float(ratio.max())
+    if worst > 1.0:
+        i = int(ratio.argmax())
+        raise AssertionError('%s: element %d got %.9g want %.9g: |diff| %.3g > rtol |want| + atol = %.3g (x%.2f; max-norm rel err %.3g)'
+                             % (name, i, float(got.reshape(-1)[i]), float(want.reshape(-1)[i]),
+                                float((got - want).abs().reshape(-1)[i]), float(bound.reshape(-1)[i]), worst,
+                                rel_err(got, want)))
+    return worst
+
+
 def load_golden(name: str):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
