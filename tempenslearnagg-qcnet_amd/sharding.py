@@ -98,7 +98,8 @@ def validation_metric_sums(data, pred: Dict[str, torch.Tensor], num_historical_s
     rec = ops.motion_metrics(pred['traj_refine'], target, prob=pred['pi_softmax'], valid_mask=agent['predict_mask'][:, T + time_shift:],
                              select=agent['category'] == 3, pos_dim=output_dim, pred_head=ops.HEAD_FROM_MOTION, target_head=-1)
     tot = rec.sum(dim=0)
-    sums = tot[[ops.METRIC_COLUMNS[c] for c in _VALIDATION_COLUMNS]]
+    # (no index tensor built from a Python list here: that would be a host-to-device copy, i.e. a host stall, per batch)
+    sums = torch.stack([tot[ops.METRIC_COLUMNS[c]] for c in _VALIDATION_COLUMNS])
     return torch.stack([sums, tot[ops.METRIC_COLUMNS['counted']].expand_as(sums)], dim=1).reshape(-1)
 
 
