@@ -171,10 +171,15 @@ class AttentionLayer(nn.Module):
     def forward(self,
                 x: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]],
                 r: Union[None, torch.Tensor, NormalizedEdgeFeatures],
-                edge_index: Union[torch.Tensor, CSRGraph]) -> torch.Tensor:
+                edge_index: Union[torch.Tensor, CSRGraph],
+                source_cache: Optional[dict] = None) -> torch.Tensor:
         """``r``: the relation's positional embedding, one row per edge of ``edge_index`` in its order (for a
         mode-replicated CSRGraph: one row per *base* edge), either raw (reference semantics) or already
-        row-normalised (``NormalizedEdgeFeatures``)."""
+        row-normalised (``NormalizedEdgeFeatures``).
+        ``source_cache`` (bipartite calls only; not in the reference): a dict owned by the caller in which the layer keeps
+        the key / value projections of ``x[0]``.  A caller that applies this layer several times to the SAME source rows
+        (the decoder's recurrent proposal steps, modules/qcnet_decoder.py:219-227) passes the same dict and the projections
+        are computed once; the caller guarantees ``x[0]`` and the layer's weights do not change while it holds the dict."""
         if self.training and self.dropout > 0:
             raise RuntimeError('AttentionLayer is inference-only: call .eval() (dropout is not implemented)')
         packs = self._kernel_packs()
@@ -203,7 +208,12 @@ class AttentionLayer(nn.Module):
         # pre: LayerNorm + q/k/v/s projections (one or two launches)
         if not single:
             ln_s, ln_d = self.attn_prenorm_x_src, self.attn_prenorm_x_dst
-            (k, v), _ = ops.ln_linear(x_src, ln_s.weight, ln_s.bias, *packs['pre_src'], mode=mode)
+            kv = source_cache.get(self) if source_cache is not None else None
+            if kv is None or kv[0].size(0) != n_src:
+                kv, _ = ops.ln_linear(x_src, ln_s.weight, ln_s.bias, *packs['pre_src'], mode=mode)
+                if source_cache is not None:
+                    source_cache[self] = kv
+            k, v = kv
             (q, s), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'], mode=mode)
         else:
             ln = self.attn_prenorm_x_src

@@ -126,7 +126,7 @@ class QCNetDecoder(nn.Module):
     _mode_key = 'm'
 
     def _cross_stack(self, stage: str, m: torch.Tensor, x_t, x_pl, x_a, r_t2m, r_pl2m, r_a2m,
-                     g_t2m, g_pl2m, g_a2m, g_m2m) -> torch.Tensor:
+                     g_t2m, g_pl2m, g_a2m, g_m2m, source_cache: Optional[dict] = None) -> torch.Tensor:
         K, C = self.num_modes, self.hidden_dim
         t2m = getattr(self, 't2m_%s_attn_layers' % stage)
         pl2m = getattr(self, 'pl2m_%s_attn_layers' % stage)
@@ -136,14 +136,22 @@ class QCNetDecoder(nn.Module):
         # agent-major throughout and the four transposes per layer pair disappear.
         m = m.reshape(-1, C)
         for i in range(self.num_layers):
-            m = t2m[i]((x_t, m), r_t2m, g_t2m)
-            m = pl2m[i]((x_pl, m), r_pl2m, g_pl2m)
-            m = a2m[i]((x_a, m), r_a2m, g_a2m)
+            m = t2m[i]((x_t, m), r_t2m, g_t2m, source_cache)
+            m = pl2m[i]((x_pl, m), r_pl2m, g_pl2m, source_cache)
+            m = a2m[i]((x_a, m), r_a2m, g_a2m, source_cache)
         m = getattr(self, 'm2m_%s_attn_layer' % stage)(m, None, g_m2m)
         return m.reshape(-1, K, C)
 
     def _decode(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int,
-                temporal_m: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
+                temporal_m: Optional[torch.Tensor], return_edge_index: bool = True) -> Dict[str, torch.Tensor]:
+        return self._refine_phase(self._propose_phase(data, scene_enc, time_shift, return_edge_index), temporal_m)
+
+    def _propose_phase(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int,
+                       return_edge_index: bool = True) -> dict:
+        """Everything up to and including the GRU re-encoding of the proposals (reference :141-257): graphs, the recurrent
+        proposal steps, the trajectory embedding.  Independent of ``temporal_m`` — TemporalAggregate's copy of this phase
+        can therefore run beside the ten-frame decoder pass whose mode queries it later sums in (see
+        predictors/temp_ens_learn_agg.py)."""
         T, C, K, ts = self.num_historical_steps, self.hidden_dim, self.num_modes, int(time_shift)
         Tf, OD = self.num_future_steps, self.output_dim
         agent = data['agent']
@@ -193,7 +201,10 @@ class QCNetDecoder(nn.Module):
             # One positional embedding / edge list per (step, agent) pair; the K mode queries of the agent share it
             # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
             r_t2m = NormalizedEdgeFeatures(self.r_t2m_emb(continuous_inputs=r_t2m, categorical_embs=None, normalized_output=r_fmt))
-            ei_t2m = mask_outer_edges(mask_src, mask_dst)
+            # the reference's K-fold replicated COO lists (:169-170,190-191,208-210,213) are outputs for inspection / parity
+            # checks only — the kernels work on the base lists — and are built on request (one enumeration launch with a
+            # host round trip and two K-fold concatenations per call otherwise)
+            ei_t2m = mask_outer_edges(mask_src, mask_dst) if return_edge_index else None
             g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
             col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
             col = col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt)
@@ -208,7 +219,9 @@ class QCNetDecoder(nn.Module):
             ei_pl2m_1, _ = ops.radius_pairs(pos_m, pos_pl, self.pl2m_radius, ptr_a, ptr_p, 300, mask_x=dst_ok)
             r_pl2m = NormalizedEdgeFeatures(self.r_pl2m_emb(
                 continuous_inputs=rel_geometry(pos_pl, pos_m, orient_pl, head_m, ei_pl2m_1), categorical_embs=None, normalized_output=r_fmt))
-            ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
+            ei_pl2m = None
+            if return_edge_index:
+                ei_pl2m = torch.cat([ei_pl2m_1 + i * ei_pl2m_1.new_tensor([[P], [A]]) for i in range(K)], dim=1)
             g_pl2m = CSRGraph.from_edge_index(ei_pl2m_1, P, A, validate=False)
             if n_pl_rows != P:
                 g_pl2m = g_pl2m.fold_sources(n_pl_rows)
@@ -219,7 +232,7 @@ class QCNetDecoder(nn.Module):
                                                  mask_x=src_ok, mask_y=dst_ok, y_first=False)
             r_a2m = NormalizedEdgeFeatures(self.r_a2m_emb(
                 continuous_inputs=rel_geometry(pos_m, pos_m, head_m, head_m, ei_a2m_1), categorical_embs=None, normalized_output=r_fmt))
-            ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1)
+            ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1) if return_edge_index else None
             g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_a2m)
 
             ei_m2m = mask_outer_edges(mask_dst, mask_dst)
@@ -234,8 +247,11 @@ class QCNetDecoder(nn.Module):
         graphs = (x_t, x_pl, x_a, r_t2m, r_pl2m, r_a2m, g_t2m, g_pl2m, g_a2m, g_m2m)
         locs: List[torch.Tensor] = []
         scales: List[torch.Tensor] = []
+        # the recurrent proposal steps apply the SAME layers to the SAME source rows: their key / value projections are
+        # computed in the first step and kept (the reference recomputes them in every step, :219-227)
+        source_cache: dict = {}
         for _ in range(self.num_recurrent_steps):
-            m = self._cross_stack('propose', m, *graphs)
+            m = self._cross_stack('propose', m, *graphs, source_cache=source_cache)
             loc, scale = MLPLayer.fused([self.to_loc_propose_pos, self.to_scale_propose_pos], m, self._head_cache('propose'))
             locs.append(loc)
             scales.append(scale)
@@ -251,7 +267,18 @@ class QCNetDecoder(nn.Module):
         gi = ops.fourier_linear(loc_propose_pos.detach().reshape(-1, OD).contiguous().float(), OD,
                                 self.y_emb.packed_weights(), wih_t, b_ih, folded=fold, mode=mm_mode)   # y_emb + the GRU's input half, one launch
         m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0, mode=mm_mode)
-        m = self._fuse_modes(m, temporal_m)
+        return dict(m=m, graphs=graphs, loc_propose_pos=loc_propose_pos, scale_propose_pos=scale_propose_pos,
+                    loc_propose_head=loc_propose_head, conc_propose_head=conc_propose_head, A=A,
+                    edges=(ei_pl2m_1, ei_t2m, ei_pl2m, ei_a2m, ei_m2m))
+
+    def _refine_phase(self, state: dict, temporal_m: Optional[torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Mode fusion hook + refinement stack + heads (reference :258-294)."""
+        K, Tf, OD = self.num_modes, self.num_future_steps, self.output_dim
+        A, graphs = state['A'], state['graphs']
+        loc_propose_pos, scale_propose_pos = state['loc_propose_pos'], state['scale_propose_pos']
+        loc_propose_head, conc_propose_head = state['loc_propose_head'], state['conc_propose_head']
+        ei_pl2m_1, ei_t2m, ei_pl2m, ei_a2m, ei_m2m = state['edges']
+        m = self._fuse_modes(state['m'], temporal_m)
         m = self._cross_stack('refine', m, *graphs)
 
         loc_ref, scale_ref, pi = MLPLayer.fused([self.to_loc_refine_pos, self.to_scale_refine_pos, self.to_pi], m,
@@ -274,5 +301,8 @@ class QCNetDecoder(nn.Module):
             'edge_index_t2m': ei_t2m, 'edge_index_pl2m': ei_pl2m, 'edge_index_a2m': ei_a2m, 'edge_index_m2m': ei_m2m,
         }
 
-    def forward(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int) -> Dict[str, torch.Tensor]:
-        return self._decode(data, scene_enc, time_shift, None)
+    def forward(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int,
+                return_edge_index: bool = True) -> Dict[str, torch.Tensor]:
+        """``return_edge_index=False`` (not in the reference): leave the K-fold replicated ``edge_index_*`` lists out of
+        the result (None) — nothing downstream of the predictors reads them."""
+        return self._decode(data, scene_enc, time_shift, None, return_edge_index)

@@ -22,5 +22,14 @@ class TemporalAggregate(QCNetDecoder):
         return stacked.sum(dim=1).reshape(-1, C)
 
     def forward(self, temporal_m: torch.Tensor, data, scene_enc: Mapping[str, torch.Tensor],
-                time_shift: int) -> Dict[str, torch.Tensor]:
-        return self._decode(data, scene_enc, time_shift, temporal_m)
+                time_shift: int, return_edge_index: bool = True) -> Dict[str, torch.Tensor]:
+        return self._decode(data, scene_enc, time_shift, temporal_m, return_edge_index)
+
+    def propose(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int, return_edge_index: bool = True) -> dict:
+        """The half of ``forward`` that does not depend on ``temporal_m`` (reference :141-259); ``refine`` finishes it.
+        ``forward(temporal_m, ...) == refine(propose(...), temporal_m)``."""
+        return self._propose_phase(data, scene_enc, time_shift, return_edge_index)
+
+    def refine(self, state: dict, temporal_m: torch.Tensor) -> Dict[str, torch.Tensor]:
+        return self._refine_phase(state, temporal_m)
+

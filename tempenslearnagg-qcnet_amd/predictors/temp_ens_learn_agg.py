@@ -6,6 +6,7 @@ Keeps the sub-module names ``base_model`` (a frozen QCNetSliding, reference :26)
 Training (losses, optimiser, Lightning hooks) and checkpoint download are outside the hot path: the model is
 built from explicit hyper-parameters instead of ``load_from_checkpoint``.
 """
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -15,7 +16,16 @@ import torch.nn.functional as F
 from .. import ops
 from ..metrics import MotionMetrics
 from ..modules import TemporalAggregate
-from ..utils.prep import inputs_ready, run_prep
+from ..utils.prep import _record, inputs_ready, run_prep
+
+_AGG_STREAMS: Dict[int, 'torch.cuda.Stream'] = {}
+
+
+def _aggregate_stream(device: torch.device) -> 'torch.cuda.Stream':
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _AGG_STREAMS:
+        _AGG_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return _AGG_STREAMS[idx]
 from .qcnet_sliding import QCNetSliding
 
 
@@ -50,6 +60,8 @@ class TempEnsLearnAgg(nn.Module):
         # in its first num_layers * time_span steps, of which the decoder reads at most a few
         # (modules/qcnet_agent_encoder.py forward_frames_streaming).
         self.stream_encoder = share_map_encoding
+        # TemporalAggregate's proposal half beside the ten-frame decoder pass (QCN_OVERLAP_AGGREGATE=0: behind it)
+        self.overlap_aggregate = os.environ.get('QCN_OVERLAP_AGGREGATE', '1') != '0'
         # Brier / minADE / minADE_best / minAHE / minFDE / minFHE / MR of the reference (:96-102), fed by one launch
         self.metrics = MotionMetrics(max_guesses=6)
 
@@ -108,9 +120,27 @@ class TempEnsLearnAgg(nn.Module):
             x_a = enc.agent_encoder.forward_frames(data, map_enc, cache)                           # [F * A, T, C]
             scene = {'x_a': x_a, 'x_pl': x_pl_frames}
             scene_last = {'x_a': x_a[(n_f - 1) * A:], 'x_pl': map_enc['x_pl']}
-        pred = dec(frames, scene, 1)
+        # The aggregation layer's proposal half (its own weights, the last frame's scene) does not depend on the ten frames'
+        # mode queries: it runs on a stream of its own BESIDE the ten-frame decoder pass — one tenth of its rows per launch,
+        # i.e. ~100 launches that fill a fraction of the GPU each and would otherwise run one after the other behind it.
+        agg = self.temporal_aggregate_layer
+        state = None
+        if self.overlap_aggregate and dev.type == 'cuda':
+            main = torch.cuda.current_stream(dev)
+            side = _aggregate_stream(dev)
+            side.wait_stream(main)                  # the encoder's outputs
+            with torch.cuda.stream(side):
+                state = agg.propose(data, scene_last, n_f, return_edge_index=False)
+                done = side.record_event()
+        pred = dec(frames, scene, 1, return_edge_index=False)
         temporal_m = pred['m'].view(n_f, A, self.num_modes, self.hidden_dim).transpose(0, 1)
-        return self._finish(self.temporal_aggregate_layer(temporal_m, data, scene_last, n_f))
+        if state is None:
+            state = agg.propose(data, scene_last, n_f, return_edge_index=False)
+        else:
+            _record(state, main, set())             # produced on the side stream, consumed (and freed) on the main stream
+            _record(scene_last, side, set())
+            main.wait_event(done)
+        return self._finish(agg.refine(state, temporal_m))
 
     @torch.no_grad()
     def predict(self, data) -> Dict[str, torch.Tensor]:
