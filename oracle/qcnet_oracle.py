@@ -345,8 +345,8 @@ def _is_batch(data) -> bool:
 
 
 def map_encoder(sd: Mapping[str, Tensor], p: str, data, hp: Mapping[str, object]) -> Dict[str, Tensor]:
-    """modules/qcnet_map_encoder.py:95-173 (input_dim == 2 branch of argoverse_v2)."""
-    assert hp['input_dim'] == 2
+    """modules/qcnet_map_encoder.py:95-173 (argoverse_v2; input_dim 2 or 3)."""
+    assert hp['input_dim'] in (2, 3)
     C, T = hp['hidden_dim'], hp['num_historical_steps']
     H, D = hp['num_heads'], hp['head_dim']
     pos_pt = data['map_point']['position'][:, :2]
@@ -358,11 +358,23 @@ def map_encoder(sd: Mapping[str, Tensor], p: str, data, hp: Mapping[str, object]
                 sd[p + 'side_pt_emb.weight'][data['map_point']['side'].long()]]
     x_pl_cat = [sd[p + 'type_pl_emb.weight'][data['map_polygon']['type'].long()],        # :113-114
                 sd[p + 'int_pl_emb.weight'][data['map_polygon']['is_intersection'].long()]]
-    x_pt = fourier_embedding(sd, p + 'x_pt_emb.', data['map_point']['magnitude'].unsqueeze(-1), x_pt_cat)
-    x_pl = fourier_embedding(sd, p + 'x_pl_emb.', None, x_pl_cat)
+    dim3 = hp.get('input_dim', 2) == 3                                                   # :103-108
+    if dim3:
+        x_pt_in = torch.stack([data['map_point']['magnitude'], data['map_point']['height']], dim=-1)
+        x_pl_in = data['map_polygon']['height'].unsqueeze(-1)
+    else:
+        x_pt_in, x_pl_in = data['map_point']['magnitude'].unsqueeze(-1), None
+    x_pt = fourier_embedding(sd, p + 'x_pt_emb.', x_pt_in, x_pt_cat)
+    x_pl = fourier_embedding(sd, p + 'x_pl_emb.', x_pl_in, x_pl_cat)
+
+    def with_dz(r, ei, src_store):   # input_dim == 3: [dist, angle, dz, d_orient] (:129-135,156-162)
+        if not dim3:
+            return r
+        dz = data[src_store]['position'][ei[0], 2] - data['map_polygon']['position'][ei[1], 2]
+        return torch.stack([r[:, 0], r[:, 1], dz, r[:, 2]], dim=-1)
 
     ei_pt2pl = data['map_point', 'to', 'map_polygon']['edge_index']                      # :120-138
-    r_pt2pl = rel_geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl)
+    r_pt2pl = with_dz(rel_geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl), ei_pt2pl, 'map_point')
     r_pt2pl = fourier_embedding(sd, p + 'r_pt2pl_emb.', r_pt2pl, None)
 
     ei_data = data['map_polygon', 'to', 'map_polygon']['edge_index']                     # :140-147
@@ -372,7 +384,7 @@ def map_encoder(sd: Mapping[str, Tensor], p: str, data, hp: Mapping[str, object]
     type_data = data['map_polygon', 'to', 'map_polygon']['type']
     ei_pl2pl, type_pl2pl = merge_edges([ei_rad, ei_data],
                                        [type_data.new_zeros(ei_rad.size(1), dtype=torch.uint8), type_data])
-    r_pl2pl = rel_geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl)               # :148-155
+    r_pl2pl = with_dz(rel_geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl), ei_pl2pl, 'map_polygon')   # :148-162
     r_pl2pl = fourier_embedding(sd, p + 'r_pl2pl_emb.', r_pl2pl,
                                 [sd[p + 'type_pl2pl_emb.weight'][type_pl2pl.long()]])    # :165
 
@@ -457,8 +469,7 @@ def decoder(sd: Mapping[str, Tensor], p: str, data, scene_enc: Mapping[str, Tens
             hp: Mapping[str, object], temporal_m: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """modules/qcnet_decoder.py:141-294; with ``temporal_m`` given, modules/temporal_aggregate.py:141-301
     (identical except the mode-query sum of :261-263 and the 'final_m' key of :299).
-    ``output_head=False`` branch only (predictors/qcnet_sliding.py:424 default)."""
-    assert not hp['output_head']
+    Both ``output_head`` branches (predictors/qcnet_sliding.py:424 defaults it to False)."""
     C, T, K = hp['hidden_dim'], hp['num_historical_steps'], hp['num_modes']
     Tf, R, OD = hp['num_future_steps'], hp['num_recurrent_steps'], hp['output_dim']
     H, D, L = hp['num_heads'], hp['head_dim'], hp['num_dec_layers']
@@ -517,17 +528,27 @@ def decoder(sd: Mapping[str, Tensor], p: str, data, scene_enc: Mapping[str, Tens
         m = attention_layer(sd, '%sm2m_%s_attn_layer.' % (p, stage), m, None, ei_m2m, H, D)   # :227 / :264
         return m.reshape(-1, K, C)
 
-    locs, scales = [], []
-    for _ in range(R):                                                                   # :219-230
+    out_head = bool(hp.get('output_head', False))
+    locs, scales, hlocs, hconcs = [], [], [], []
+    for _ in range(R):                                                                   # :219-233
         m = cross_stack(m, 'propose')
         locs.append(mlp_layer(sd, p + 'to_loc_propose_pos.', m))
         scales.append(mlp_layer(sd, p + 'to_scale_propose_pos.', m))
+        if out_head:
+            hlocs.append(mlp_layer(sd, p + 'to_loc_propose_head.', m))
+            hconcs.append(mlp_layer(sd, p + 'to_conc_propose_head.', m))
     loc_propose_pos = torch.cumsum(torch.cat(locs, dim=-1).view(-1, K, Tf, OD), dim=-2)  # :234-242
     scale_propose_pos = torch.cumsum(F.elu(torch.cat(scales, dim=-1).view(-1, K, Tf, OD), alpha=1.0) + 1.0,
                                      dim=-2) + 0.1
-    loc_propose_head = loc_propose_pos.new_zeros(A, K, Tf, 1)                            # :251-254
-    conc_propose_head = scale_propose_pos.new_zeros(A, K, Tf, 1)
-    m = fourier_embedding(sd, p + 'y_emb.', loc_propose_pos.reshape(-1, OD), None)       # :255
+    if out_head:                                                                         # :243-250
+        loc_propose_head = torch.cumsum(torch.tanh(torch.cat(hlocs, dim=-1).unsqueeze(-1)) * math.pi, dim=-2)
+        conc_propose_head = 1.0 / (torch.cumsum(F.elu(torch.cat(hconcs, dim=-1).unsqueeze(-1)) + 1.0, dim=-2) + 0.02)
+        m = fourier_embedding(sd, p + 'y_emb.', torch.cat([loc_propose_pos, wrap_angle(loc_propose_head)],
+                                                          dim=-1).view(-1, OD + 1), None)
+    else:
+        loc_propose_head = loc_propose_pos.new_zeros(A, K, Tf, 1)                        # :251-254
+        conc_propose_head = scale_propose_pos.new_zeros(A, K, Tf, 1)
+        m = fourier_embedding(sd, p + 'y_emb.', loc_propose_pos.reshape(-1, OD), None)   # :255
     m = m.reshape(-1, Tf, C).transpose(0, 1)                                             # :256
     h0 = sd[p + 'traj_emb_h0'].repeat(m.size(1), 1)                                      # :257
     m = gru_last_hidden(sd, p + 'traj_emb.', m, h0)
@@ -537,12 +558,17 @@ def decoder(sd: Mapping[str, Tensor], p: str, data, scene_enc: Mapping[str, Tens
     loc_refine_pos = mlp_layer(sd, p + 'to_loc_refine_pos.', m).view(-1, K, Tf, OD) + loc_propose_pos   # :266-267
     scale_refine_pos = F.elu(mlp_layer(sd, p + 'to_scale_refine_pos.', m).view(-1, K, Tf, OD), alpha=1.0) + 1.0 + 0.1
     pi = mlp_layer(sd, p + 'to_pi.', m).squeeze(-1)                                      # :280
+    if out_head:                                                                         # :271-274
+        loc_refine_head = torch.tanh(mlp_layer(sd, p + 'to_loc_refine_head.', m).unsqueeze(-1)) * math.pi + loc_propose_head
+        conc_refine_head = 1.0 / (F.elu(mlp_layer(sd, p + 'to_conc_refine_head.', m).unsqueeze(-1)) + 1.0 + 0.02)
+    else:
+        loc_refine_head = loc_refine_pos.new_zeros(A, K, Tf, 1)
+        conc_refine_head = scale_refine_pos.new_zeros(A, K, Tf, 1)
     return {
         'loc_propose_pos': loc_propose_pos, 'scale_propose_pos': scale_propose_pos,
         'loc_propose_head': loc_propose_head, 'conc_propose_head': conc_propose_head,
         'loc_refine_pos': loc_refine_pos, 'scale_refine_pos': scale_refine_pos,
-        'loc_refine_head': loc_refine_pos.new_zeros(A, K, Tf, 1),
-        'conc_refine_head': scale_refine_pos.new_zeros(A, K, Tf, 1),
+        'loc_refine_head': loc_refine_head, 'conc_refine_head': conc_refine_head,
         'pi': pi, ('final_m' if temporal_m is not None else 'm'): m,
         'edge_index_pl2m_clone': ei_pl2m_1,
         'edge_index_t2m': ei_t2m, 'edge_index_pl2m': ei_pl2m, 'edge_index_a2m': ei_a2m, 'edge_index_m2m': ei_m2m,

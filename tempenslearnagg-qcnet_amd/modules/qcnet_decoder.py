@@ -5,6 +5,7 @@ The propose/refine stacks run on destination-sorted CSR graphs built once per ca
 polygon and agent features (reference :150-151) is folded away: sources are gathered from the single copy.
 ``TemporalAggregate`` shares this implementation through the ``_fuse_modes`` hook.
 """
+import math
 import os
 from typing import Dict, List, Mapping, Optional
 
@@ -15,6 +16,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..layers import attention_layer
 from ..layers import AttentionLayer, FourierEmbedding, MLPLayer, NormalizedEdgeFeatures
+from ..utils.geometry import wrap_angle
 from ..utils.graph import CSRGraph, mask_outer_edges
 from ..utils.weight_init import weight_init
 from ..utils.prep import run_prep
@@ -42,8 +44,8 @@ class QCNetDecoder(nn.Module):
                  head_dim: int,
                  dropout: float) -> None:
         super().__init__()
-        if output_head:
-            raise NotImplementedError('output_head=True (heading outputs) is outside the AV2 configuration')
+        if output_head and num_future_steps % num_recurrent_steps != 0:
+            raise ValueError('num_future_steps must be divisible by num_recurrent_steps')
         if (num_future_steps * output_dim) % num_recurrent_steps != 0:
             raise ValueError('num_future_steps * output_dim must be divisible by num_recurrent_steps')
         self.dataset = dataset
@@ -83,10 +85,17 @@ class QCNetDecoder(nn.Module):
                                           output_dim=num_future_steps * output_dim)
         self.to_scale_refine_pos = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim,
                                             output_dim=num_future_steps * output_dim)
-        self.to_loc_propose_head = None
-        self.to_conc_propose_head = None
-        self.to_loc_refine_head = None
-        self.to_conc_refine_head = None
+        if output_head:   # heading outputs (reference :125-132)
+            head_step = num_future_steps // num_recurrent_steps
+            self.to_loc_propose_head = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=head_step)
+            self.to_conc_propose_head = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=head_step)
+            self.to_loc_refine_head = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=num_future_steps)
+            self.to_conc_refine_head = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=num_future_steps)
+        else:
+            self.to_loc_propose_head = None
+            self.to_conc_propose_head = None
+            self.to_loc_refine_head = None
+            self.to_conc_refine_head = None
         self.to_pi = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=1)
         self.apply(weight_init)
 
@@ -247,6 +256,8 @@ class QCNetDecoder(nn.Module):
         graphs = (x_t, x_pl, x_a, r_t2m, r_pl2m, r_a2m, g_t2m, g_pl2m, g_a2m, g_m2m)
         locs: List[torch.Tensor] = []
         scales: List[torch.Tensor] = []
+        hlocs: List[torch.Tensor] = []
+        hconcs: List[torch.Tensor] = []
         # the recurrent proposal steps apply the SAME layers to the SAME source rows: their key / value projections are
         # computed in the first step and kept (the reference recomputes them in every step, :219-227)
         source_cache: dict = {}
@@ -255,16 +266,28 @@ class QCNetDecoder(nn.Module):
             loc, scale = MLPLayer.fused([self.to_loc_propose_pos, self.to_scale_propose_pos], m, self._head_cache('propose'))
             locs.append(loc)
             scales.append(scale)
+            if self.output_head:
+                hloc, hconc = MLPLayer.fused([self.to_loc_propose_head, self.to_conc_propose_head], m,
+                                             self._head_cache('propose_head'))
+                hlocs.append(hloc)
+                hconcs.append(hconc)
         loc_propose_pos = torch.cumsum(torch.cat(locs, dim=-1).view(-1, K, Tf, OD), dim=-2)
         scale_propose_pos = torch.cumsum(F.elu(torch.cat(scales, dim=-1).view(-1, K, Tf, OD), alpha=1.0) + 1.0,
                                          dim=-2) + 0.1
-        loc_propose_head = loc_propose_pos.new_zeros((A, K, Tf, 1))
-        conc_propose_head = scale_propose_pos.new_zeros((A, K, Tf, 1))
+        if self.output_head:   # reference :243-250: cumulative headings, concentrations; y_emb sees [x, y, wrapped heading]
+            loc_propose_head = torch.cumsum(torch.tanh(torch.cat(hlocs, dim=-1).unsqueeze(-1)) * math.pi, dim=-2)
+            conc_propose_head = 1.0 / (torch.cumsum(F.elu(torch.cat(hconcs, dim=-1).unsqueeze(-1)) + 1.0, dim=-2) + 0.02)
+            y_in = torch.cat([loc_propose_pos.detach(), wrap_angle(loc_propose_head.detach())], dim=-1)
+        else:
+            loc_propose_head = loc_propose_pos.new_zeros((A, K, Tf, 1))
+            conc_propose_head = scale_propose_pos.new_zeros((A, K, Tf, 1))
+            y_in = loc_propose_pos.detach()
+        y_dim = OD + int(self.output_head)
 
         # trajectory re-encoding: Fourier embedding of the proposed way-points, GRU over the Tf steps, last hidden state
         # (reference :255-257); row n * Tf + t of the embedding is step t of mode query n
         wih_t, b_ih, whh, b_hh, h0, mm_mode, fold = self._gru_packs()
-        gi = ops.fourier_linear(loc_propose_pos.detach().reshape(-1, OD).contiguous().float(), OD,
+        gi = ops.fourier_linear(y_in.reshape(-1, y_dim).contiguous().float(), y_dim,
                                 self.y_emb.packed_weights(), wih_t, b_ih, folded=fold, mode=mm_mode)   # y_emb + the GRU's input half, one launch
         m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0, mode=mm_mode)
         return dict(m=m, graphs=graphs, loc_propose_pos=loc_propose_pos, scale_propose_pos=scale_propose_pos,
@@ -283,6 +306,10 @@ class QCNetDecoder(nn.Module):
 
         loc_ref, scale_ref, pi = MLPLayer.fused([self.to_loc_refine_pos, self.to_scale_refine_pos, self.to_pi], m,
                                                 self._head_cache('refine'))
+        if self.output_head:   # reference :271-274
+            hloc, hconc = MLPLayer.fused([self.to_loc_refine_head, self.to_conc_refine_head], m, self._head_cache('refine_head'))
+            loc_refine_head = torch.tanh(hloc.view(-1, K, Tf, 1)) * math.pi + loc_propose_head.detach()
+            conc_refine_head = 1.0 / (F.elu(hconc.view(-1, K, Tf, 1)) + 1.0 + 0.02)
         loc_refine_pos = loc_ref.view(-1, K, Tf, OD) + loc_propose_pos.detach()
         scale_refine_pos = F.elu(scale_ref.view(-1, K, Tf, OD), alpha=1.0) + 1.0 + 0.1
         pi = pi.squeeze(-1)
@@ -293,8 +320,8 @@ class QCNetDecoder(nn.Module):
             'conc_propose_head': conc_propose_head,
             'loc_refine_pos': loc_refine_pos,
             'scale_refine_pos': scale_refine_pos,
-            'loc_refine_head': loc_refine_pos.new_zeros((A, K, Tf, 1)),
-            'conc_refine_head': scale_refine_pos.new_zeros((A, K, Tf, 1)),
+            'loc_refine_head': loc_refine_head if self.output_head else loc_refine_pos.new_zeros((A, K, Tf, 1)),
+            'conc_refine_head': conc_refine_head if self.output_head else scale_refine_pos.new_zeros((A, K, Tf, 1)),
             'pi': pi,
             self._mode_key: m,
             'edge_index_pl2m_clone': ei_pl2m_1,

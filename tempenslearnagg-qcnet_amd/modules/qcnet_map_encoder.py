@@ -34,8 +34,8 @@ class QCNetMapEncoder(nn.Module):
         super().__init__()
         if dataset != 'argoverse_v2':
             raise ValueError('{} is not a valid dataset'.format(dataset))
-        if input_dim != 2:
-            raise NotImplementedError('only the 2-D AV2 configuration (input_dim=2) is implemented')
+        if input_dim not in (2, 3):
+            raise ValueError('{} is not a valid dimension'.format(input_dim))
         self.dataset = dataset
         self.input_dim = input_dim
         self.hidden_dim = hidden_dim
@@ -50,7 +50,8 @@ class QCNetMapEncoder(nn.Module):
         for name, vocab in (('type_pt_emb', 17), ('side_pt_emb', 3), ('type_pl_emb', 4), ('int_pl_emb', 3),
                             ('type_pl2pl_emb', 5)):
             setattr(self, name, nn.Embedding(vocab, hidden_dim))
-        for name, dim in (('x_pt_emb', 1), ('x_pl_emb', 0), ('r_pt2pl_emb', 3), ('r_pl2pl_emb', 3)):
+        dims = (1, 0, 3, 3) if input_dim == 2 else (2, 1, 4, 4)       # reference :56-65: 3-D adds heights and a dz column
+        for name, dim in zip(('x_pt_emb', 'x_pl_emb', 'r_pt2pl_emb', 'r_pl2pl_emb'), dims):
             setattr(self, name, FourierEmbedding(input_dim=dim, hidden_dim=hidden_dim, num_freq_bands=num_freq_bands))
         layer = dict(hidden_dim=hidden_dim, num_heads=num_heads, head_dim=head_dim, dropout=dropout, has_pos_emb=True)
         self.pt2pl_layers = nn.ModuleList([AttentionLayer(bipartite=True, **layer) for _ in range(num_layers)])
@@ -68,16 +69,32 @@ class QCNetMapEncoder(nn.Module):
             orient_pl = pl['orientation'].contiguous()
             n_pt, n_pl = pos_pt.size(0), pos_pl.size(0)
 
-            x_pt = self.x_pt_emb(continuous_inputs=pt['magnitude'].unsqueeze(-1),
+            dim3 = self.input_dim == 3
+            if dim3:   # reference :106-108
+                x_pt_in = torch.stack([pt['magnitude'], pt['height']], dim=-1)
+                x_pl_in = pl['height'].unsqueeze(-1)
+                z_pt, z_pl = pt['position'][:, 2], pl['position'][:, 2]
+            else:
+                x_pt_in, x_pl_in = pt['magnitude'].unsqueeze(-1), None
+
+            def geometry(pos_s, pos_d, orient_s, orient_d, ei, z_s=None):
+                """[dist, angle, d_orient] rows (one kernel); 3-D: the height difference as third column (:129-135,156-162)"""
+                r = rel_geometry(pos_s, pos_d, orient_s, orient_d, ei)
+                if not dim3:
+                    return r
+                return torch.stack([r[:, 0], r[:, 1], z_s[ei[0]] - z_pl[ei[1]], r[:, 2]], dim=-1).contiguous()
+
+            x_pt = self.x_pt_emb(continuous_inputs=x_pt_in,
                                  categorical_embs=[self.type_pt_emb(pt['type'].long()), self.side_pt_emb(pt['side'].long())])
-            x_pl = self.x_pl_emb(continuous_inputs=None,
+            x_pl = self.x_pl_emb(continuous_inputs=x_pl_in,
                                  categorical_embs=[self.type_pl_emb(pl['type'].long()),
                                                    self.int_pl_emb(pl['is_intersection'].long())])
 
             ei_pt2pl = data['map_point', 'to', 'map_polygon']['edge_index']
             g_pt2pl = CSRGraph.from_edge_index(ei_pt2pl, n_pt, n_pl)
             r_pt2pl = NormalizedEdgeFeatures(self.r_pt2pl_emb(
-                continuous_inputs=rel_geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl), categorical_embs=None, normalized_output=True))
+                continuous_inputs=geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl, z_pt if dim3 else None),
+                categorical_embs=None, normalized_output=True))
 
             ptr_pl = node_ptr(data, 'map_polygon', pos_pl.device)
             ei_radius, _ = ops.radius_pairs(pos_pl, pos_pl, self.pl2pl_radius, ptr_pl, ptr_pl, 300 + 1, drop_self=True,
@@ -88,7 +105,7 @@ class QCNetMapEncoder(nn.Module):
                 edge_attrs=[type_data.new_zeros(ei_radius.size(1), dtype=torch.uint8), type_data], reduce='max')
             g_pl2pl = CSRGraph.from_edge_index(ei_pl2pl, n_pl, n_pl)
             r_pl2pl = NormalizedEdgeFeatures(self.r_pl2pl_emb(
-                continuous_inputs=rel_geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl),
+                continuous_inputs=geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl, z_pl if dim3 else None),
                 categorical_embs=[self.type_pl2pl_emb(type_pl2pl.long())], normalized_output=True))
 
             return x_pt, x_pl, g_pt2pl, r_pt2pl, g_pl2pl, r_pl2pl, ei_pl2pl, type_pl2pl

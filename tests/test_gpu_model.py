@@ -416,3 +416,61 @@ def test_dense_scene_with_neighbour_cap_vs_oracle():
         loop = model.predict(batch.to(DEV))
     for k in ('traj_refine', 'pi_softmax'):
         assert rel_err(fast[k], loop[k]) < 1e-5, k
+
+
+def test_scenario_files_predict_like_in_memory_scenarios(tmp_path):
+    """SURVEY 8(f) N4 on the GPU: scenarios written in the reference's processed-file format
+    (datasets/argoverse_v2_dataset.py:203-209: one pickled dict per scenario under <root>/<split>/processed_qcnet/) and read
+    back through ProcessedScenarioDataset + its collate give bit-identical predictions to the in-memory scenarios, through
+    the full ten-frame pass; TargetBuilder (transforms/target_builder.py) as the dataset's transform adds the training
+    target without changing them."""
+    from tempenslearnagg_qcnet_amd.datasets import ProcessedScenarioDataset, save_scenario
+    from tempenslearnagg_qcnet_amd.transforms import TargetBuilder
+    cfg = config_scene('cfg1')
+    ids = [11, 4, 7]
+    d = tmp_path / 'val' / 'processed_qcnet'
+    d.mkdir(parents=True)
+    for i in ids:
+        s = make_scenario(i, **cfg['scene'])
+        s['scenario_id'] = 'scenario-%04d' % i
+        save_scenario(s, str(d / ('%04d.pkl' % i)))
+    ds = ProcessedScenarioDataset(str(tmp_path), 'val', transform=TargetBuilder(50, 60))
+    assert len(ds) == 3
+    from_files = next(iter(ds.batches(3)))                        # file order: 0004, 0007, 0011
+    assert from_files['scenario_id'] == ['scenario-0004', 'scenario-0007', 'scenario-0011']
+    assert tuple(from_files['agent']['target'].shape) == (150, 60, 4)
+    in_memory = make_batch(sorted(ids), **cfg['scene'])
+    model = _model(cfg, seed=2).to(DEV)
+    with torch.no_grad():
+        got = model.predict(from_files.to(DEV))
+        want = model.predict(in_memory.to(DEV))
+    for k in ('traj_refine', 'pi_softmax', 'final_m'):
+        assert torch.equal(got[k], want[k]), k
+
+
+def test_output_head_and_3d_map_branches_vs_oracle():
+    """The two branches off the AV2 defaults (VERDICT r1 missing item 5): ``output_head=True`` — heading / concentration heads,
+    a three-input trajectory embedding (modules/qcnet_decoder.py:125-132,243-249,271-274) — and ``input_dim=3`` — point /
+    polygon heights as inputs and a height-difference column in both map relations (modules/qcnet_map_encoder.py:59-63,
+    106-108,129-135,156-162) — against the oracle, edge lists bit-exact."""
+    cfg = config_scene('tiny')
+    hp = dict(cfg['hparams'], output_head=True, input_dim=3)
+    model = _model(dict(hparams=hp), seed=12)
+    assert model.base_model.decoder.y_emb.input_dim == 3 and model.base_model.encoder.map_encoder.r_pl2pl_emb.input_dim == 4
+    assert 'base_model.decoder.to_loc_refine_head.mlp.3.weight' in model.state_dict()
+    sd = cpu_state_dict(model)
+    batch = make_batch([0, 1, 2], **cfg['scene'])
+    gen = torch.Generator().manual_seed(5)
+    for store in ('map_point', 'map_polygon'):                       # the synthetic scenes are flat: give them relief
+        z = torch.randn(batch[store]['position'].size(0), generator=gen) * 2.0
+        batch[store]['position'][:, 2] = z
+        batch[store]['height'] = z.abs() * 0.1
+    with torch.no_grad():
+        want_pred, want_enc = oracle.qcnet_forward(sd, batch, 6, hp, p='base_model.')
+        got_pred, got_enc = model.to(DEV)(batch.to(DEV), 6)
+    _check_edges(got_enc, want_enc, EDGE_KEYS_ENC)
+    _check_edges(got_pred, want_pred, EDGE_KEYS_DEC)
+    assert_close(got_enc['x_pl'][:, 0], want_enc['x_pl'][:, 0], 'x_pl')
+    for k in OUT_KEYS + ('m', 'loc_propose_head', 'conc_propose_head', 'loc_refine_head', 'conc_refine_head'):
+        assert float(want_pred[k].abs().max()) > 0, k
+        assert_close(got_pred[k], want_pred[k], k)
