@@ -225,18 +225,25 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeExact>
 // split: 8 k16-steps x 4 tiles x (hi*hi + hi*lo + lo*hi).  LDS image of a matrix: [k16-step j][tile t][plane p][lane]
 // 16-byte fragments (8 f16: out = 32 t + (lane & 31), k = the 8 features of registers 8 (j & 1) .. + 7 of v[j >> 1]).
 // The accumulators are moved to the operands' scale and back by two exact power-of-two multiplies.
-template <int WAVES>
-__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w,
-                                     const float *__restrict__ mscale, int lane, const float *__restrict__ next = nullptr,
-                                     f32x4 *next_dst = nullptr, int wave = 0)
+// SCALE = false: the accumulators are taken and left in the operands' scale (gemm_add below starts them at zero and folds the
+// way back into the fma that adds the bias).
+template <int WAVES, bool SCALE>
+__device__ __forceinline__ void gemm_split_core(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w,
+                                                const float *__restrict__ mscale, int lane, const float *__restrict__ next,
+                                                f32x4 *next_dst, int wave)
 {
     constexpr int kPieces = (kMatVec4 / 64) / WAVES;
     constexpr int kEvery = 32 / kPieces > 0 ? 32 / kPieces : 1;
     constexpr int kPerSlot = kPieces > 32 ? kPieces / 32 : 1;
     const float S = in.sc * mscale[0], U = in.usc * mscale[1];
+    if constexpr (SCALE) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] *= S;
+        for (int t = 0; t < 4; ++t) acc[t] *= S;
+    }
     f32x4 nh = w[lane], nl = w[64 + lane];
+#ifdef QCN_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(QCN_GEMM_PRIO);
+#endif
 #pragma unroll
     for (int g = 0; g < 32; ++g) {            // g = 4 j + t
         const int j = g >> 2, t = g & 3;
@@ -265,8 +272,21 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeSplit>
 #endif
         __builtin_amdgcn_sched_barrier(0);
     }
+#ifdef QCN_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    if constexpr (SCALE) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) acc[t] *= U;
+        for (int t = 0; t < 4; ++t) acc[t] *= U;
+    }
+}
+
+template <int WAVES>
+__device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w,
+                                     const float *__restrict__ mscale, int lane, const float *__restrict__ next = nullptr,
+                                     f32x4 *next_dst = nullptr, int wave = 0)
+{
+    gemm_split_core<WAVES, true>(acc, in, w, mscale, lane, next, next_dst, wave);
 }
 
 // bf16: 8 k16-steps x 4 tiles, one MFMA each.  LDS image of a matrix: [k16-step j][tile t][lane] 16-byte fragments (8 bf16:
@@ -304,6 +324,55 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeBf16> 
         __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+// acc = W in + add, where add(t, q) gives the additive term (bias, rank-1 term ...) of registers 4 q .. 4 q + 3 of acc[t].
+// exact / bf16: the accumulators start at `add` (exact mode: the fp32 fma chain of an fmaf loop that starts at the bias).
+// split: they start at ZERO in the operands' scale and the term is added by the one fma per element that also scales the
+// sum back — 64 fma instead of 64 moves + 2 x 64 multiplies per GEMM, a sixth of the vector-ALU work of a GEMM + epilogue
+// phase (the rescaling factors are powers of two, so this is the same sum with the bias added last instead of first).
+template <int WAVES, int MODE, typename Add>
+__device__ __forceinline__ void gemm_add(f32x16 (&acc)[4], const Operand<MODE> &in, const f32x4 *w,
+                                         const float *__restrict__ mscale, int lane, Add add,
+                                         const float *__restrict__ next = nullptr, f32x4 *next_dst = nullptr, int wave = 0)
+{
+    if constexpr (MODE == kModeSplit) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        gemm_split_core<WAVES, false>(acc, in, w, mscale, lane, next, next_dst, wave);
+        const float U = in.usc * mscale[1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = add(t, q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = fmaf(acc[t][4 * q + j], U, a[j]);
+            }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 a = add(t, q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = a[j];
+            }
+        gemm<WAVES>(acc, in, w, mscale, lane, next, next_dst, wave);
+    }
+}
+
+// the additive term of gemm_add for a per-feature vector (bias) in LDS / global memory; nullptr: zero
+struct BiasTerm {
+    const float *vec;
+    int h;
+    __device__ __forceinline__ f32x4 operator()(int t, int q) const
+    {
+        if (vec == nullptr) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4 *>(vec + 32 * t + 8 * q + 4 * h);
+    }
+};
 
 // per-feature vector (bias, LayerNorm affine, ...) in register layout: 16 broadcast float4 loads
 __device__ __forceinline__ void load_feature_vec(f32x16 (&v)[4], const float *__restrict__ vec, int h)

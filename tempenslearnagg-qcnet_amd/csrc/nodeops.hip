@@ -30,13 +30,18 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
                                                                float *__restrict__ xn_out)
 {
     // two matrix buffers + one 4 KiB transposition block per wave (load_tile / store_tile), in ONE __shared__ array
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + WAVES * 256];
+    // (+ the biases, 4 x 128 floats: gemm_add reads them right behind a GEMM, where a global load would sit exposed)
+    // (eight-wave blocks have no LDS left for them — 160 KiB — and keep the accumulators starting at the bias)
+    constexpr bool kLdsBias = WAVES <= 4;
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + WAVES * 256 + (kLdsBias ? kC : 0)];
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave;
     f32x4 *const xpose = wlds + 2 * kMatVec4 + wave * 256;
+    float *const sbias = reinterpret_cast<float *>(wlds + 2 * kMatVec4 + WAVES * 256);
 
     stage_matrix<WAVES, MODE>(wp, wlds, wave, lane);
+    if (kLdsBias && bias != nullptr) stage_vectors<WAVES>(bias, sbias, n_out * kC, tid);   // visible after the first sync_for_stage
     f32x16 xv[4];
     load_tile(xv, x, row0, n_rows, xpose, lane);
     if (ln_g != nullptr) layer_norm<true, false>(xv, ln_g, ln_b, h, 1e-5f);
@@ -47,11 +52,18 @@ __global__ __launch_bounds__(64 * WAVES) void ln_linear_kernel(const float *__re
 #pragma unroll 1
     for (int j = 0; j < n_out; ++j) {
         f32x16 acc[4];
-        if (bias != nullptr) load_feature_vec(acc, bias + j * kC, h);
-        else fill_zero(acc);
-        sync_for_stage();   // matrix j has landed (every wave drained its DMA), buffer (j+1)&1 is no longer read
-        gemm<WAVES>(acc, xo, wlds + (j & 1) * kMatVec4, mscale + 2 * j, lane,
-                    j + 1 < n_out ? wp + (size_t)(j + 1) * kMatFloats : nullptr, wlds + ((j + 1) & 1) * kMatVec4, wave);
+        if constexpr (kLdsBias) {
+            sync_for_stage();   // matrix j has landed (every wave drained its DMA), buffer (j+1)&1 is no longer read
+            gemm_add<WAVES, MODE>(acc, xo, wlds + (j & 1) * kMatVec4, mscale + 2 * j, lane,
+                                  BiasTerm{bias != nullptr ? sbias + j * kC : nullptr, h},
+                                  j + 1 < n_out ? wp + (size_t)(j + 1) * kMatFloats : nullptr, wlds + ((j + 1) & 1) * kMatVec4, wave);
+        } else {
+            if (bias != nullptr) load_feature_vec(acc, bias + j * kC, h);
+            else fill_zero(acc);
+            sync_for_stage();
+            gemm<WAVES>(acc, xo, wlds + (j & 1) * kMatVec4, mscale + 2 * j, lane,
+                        j + 1 < n_out ? wp + (size_t)(j + 1) * kMatFloats : nullptr, wlds + ((j + 1) & 1) * kMatVec4, wave);
+        }
         float *y = j == 0 ? y0 : j == 1 ? y1 : j == 2 ? y2 : y3;
         store_tile(acc, y, row0, n_rows, xpose, lane);
     }
@@ -108,10 +120,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     // ---- gate: g = sigmoid(Wg [agg, xn] + bg)
     f32x16 va[4], acc[4];
     load_tile2(va, agg, row0, n_rows, xpose, lane);
-    load_feature_vec(acc, vec + kVBg, h);
     make_operand(op, va);
     PSTAMP(0) sync_for_stage(); PSTAMP(1)
-    gemm<WAVES>(acc, op, buf0, msc + 0, lane, mats + kMatFloats, buf1, wave);
+    gemm_add<WAVES, MODE>(acc, op, buf0, msc + 0, lane, BiasTerm{vec + kVBg, h}, mats + kMatFloats, buf1, wave);
     skew_after_gemm(skew); PSTAMP(2)
     // Blocks of up to four waves (one wave per SIMD, 512 registers): x_res is read ONCE and x1 is never parked in `out` —
     // a row the lane reads back is a scattered load (32 lines of 32 B per instruction) with its latency exposed (−5 % at
@@ -154,10 +165,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
             }
     }
     // ---- x1 = x + LN_post(Wout u + bout)
-    load_feature_vec(acc, vec + kVBout, h);
     make_operand(op, va);
     PSTAMP(0) sync_for_stage(); PSTAMP(1)
-    gemm<WAVES>(acc, op, buf0, msc + 4, lane, mats + 3 * kMatFloats, buf1, wave);
+    gemm_add<WAVES, MODE>(acc, op, buf0, msc + 4, lane, BiasTerm{vec + kVBout, h}, mats + 3 * kMatFloats, buf1, wave);
     skew_after_gemm(skew); PSTAMP(2)
     layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
     if (!kKeepRows || xn != nullptr) load_tile2(xr, xres, row0, n_rows, xpose, lane);
@@ -174,9 +184,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
 #pragma unroll 1
     for (int hb = 0; hb < 4; ++hb) {
         const float *w1 = mats + (size_t)(3 + 2 * hb) * kMatFloats;
-        load_feature_vec(acc, vec + kVB1 + hb * kC, h);
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
-        gemm<WAVES>(acc, op, buf1, msc + 2 * (3 + 2 * hb), lane, w1 + kMatFloats, buf0, wave);
+        gemm_add<WAVES, MODE>(acc, op, buf1, msc + 2 * (3 + 2 * hb), lane, BiasTerm{vec + kVB1 + hb * kC, h}, w1 + kMatFloats,
+                              buf0, wave);
         skew_after_gemm(skew); PSTAMP(2)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -241,19 +251,17 @@ __global__ __launch_bounds__(64 * WAVES) void mlp_heads_kernel(const float *__re
     for (int i = 0; i < hd.n_heads; ++i) {
         const float *vec = vecs + i * kMlpVecs;
         f32x16 acc[4];
-        load_feature_vec(acc, vec, h);
         sync_for_stage();
-        gemm<WAVES>(acc, xo, wlds + ((2 * i) & 1) * kMatVec4, msc + 4 * i, lane, pack + (size_t)(2 * i + 1) * kMatFloats,
-                    wlds + ((2 * i + 1) & 1) * kMatVec4, wave);
+        gemm_add<WAVES, MODE>(acc, xo, wlds + ((2 * i) & 1) * kMatVec4, msc + 4 * i, lane, BiasTerm{vec, h},
+                              pack + (size_t)(2 * i + 1) * kMatFloats, wlds + ((2 * i + 1) & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
         layer_norm<true, true>(acc, vec + kC, vec + 2 * kC, h, 1e-5f);
         Operand<MODE> hid;
         make_operand(hid, acc);
-        load_feature_vec(acc, vec + 3 * kC, h);
         sync_for_stage();
-        gemm<WAVES>(acc, hid, wlds + ((2 * i + 1) & 1) * kMatVec4, msc + 4 * i + 2, lane,
-                    2 * i + 2 < n_mats ? pack + (size_t)(2 * i + 2) * kMatFloats : nullptr, wlds + ((2 * i + 2) & 1) * kMatVec4,
-                    wave);
+        gemm_add<WAVES, MODE>(acc, hid, wlds + ((2 * i + 1) & 1) * kMatVec4, msc + 4 * i + 2, lane, BiasTerm{vec + 3 * kC, h},
+                              2 * i + 2 < n_mats ? pack + (size_t)(2 * i + 2) * kMatFloats : nullptr,
+                              wlds + ((2 * i + 2) & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
         if (valid) {
             const int od = hd.out_dim[i];
