@@ -212,12 +212,20 @@ int qcn_attn_modes_bf16(const float *q, const float *k, const float *v, const vo
  *   consuming AttentionLayers' attn_prenorm_r (layers/attention_layer.py:82); normalize_out == 2 writes that result
  *   as split-f16 rows instead (y = [n_rows, 256] f16, scale 2^11: the rhat_split operand of qcn_attn_modes_f32),
  *   normalize_out == 3 as bf16 rows (y = [n_rows, 128] bf16, round to nearest even: the operand of qcn_attn_modes_bf16).
- *   pack: qcn_fourier_pack_floats(input_dim) floats: the 2 input_dim + 1 chain-packed matrices
- *     [mlps.0.0.weight[:, :128] (cos | sin order above), mlps.0.3.weight, mlps.1.0.weight[:, :128], ..., to_out.2.weight]
- *   then per input dim i
- *     [freqs.weight[i] (64) | mlps.i.0.weight[:, 128] | mlps.i.0.bias | mlps.i.1.weight | mlps.i.1.bias | mlps.i.3.bias]
- *   followed by [to_out.0.weight | to_out.0.bias | to_out.2.bias], then the scale table: 32 floats, {scale, 1 / scale}
- *   per matrix in the order above.
+ *   pack: qcn_fourier_pack_floats(input_dim) floats (host packer: ops.pack_fourier), the 2 input_dim + 1 chain-packed matrices
+ *     [W1c_0 (cos | sin order above), W2c_0, W1c_1, ..., to_out.2.weight]
+ *   where W1c_i = mlps.i.0.weight[:, :128] and W2c_i = mlps.i.3.weight with the mean over the OUTPUT features removed from
+ *   every column (rows of (I - 11^T / 128) W; not in the bf16 mode): the mean of W f + b is linear in f, so the LayerNorm
+ *   behind such a layer starts at the variance.  Then per input dim i
+ *     [freqs.weight[i] (64) | centred mlps.i.0.weight[:, 128] | centred mlps.i.0.bias | mlps.i.1.weight * s1_i |
+ *      mlps.i.1.bias * s1_i | {max |freqs[i][0:32]|, max |freqs[i][32:64]|, 0, 0}]
+ *   followed by [centred sum_i mlps.i.3.bias | to_out.0.weight * so | to_out.0.bias * so | to_out.2.bias], then the scale
+ *   table (32 floats): [2 i] = 1 / (matrix scale of W1c_i), [2 input_dim] = 1 / (so x matrix scale of to_out.2),
+ *   [24] = so, [25] = 1 / so, [26] = 1 / (s1_i x matrix scale of W2c_i) — ONE value: the W2c_i are packed with matrix
+ *   scales that make it equal for every i, so their products accumulate without any work between the GEMMs.
+ *   s1_i / so (split mode; 1 otherwise) are the static power-of-two operand scales of the LayerNorm outputs: the largest
+ *   2^k with (sqrt(127) max|gamma| + max|beta|) 2^k <= 2^15 — a LayerNorm output is bounded by that whatever its input, so the
+ *   kernels split it into f16 hi + lo without scanning the row for its maximum.
  *   hidden_dim = 128, num_freq_bands = 64 only. */
 size_t qcn_fourier_pack_floats(int input_dim);
 int qcn_fourier_embed_f32(const float *x, int input_dim, const float *extra, int64_t extra_div,

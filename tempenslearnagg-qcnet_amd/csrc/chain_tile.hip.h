@@ -184,6 +184,42 @@ __device__ __forceinline__ void make_operand(Operand<kModeBf16> &o, const f32x16
         for (int i = 0; i < 8; ++i) o.v[j][i] = (__bf16)in[j >> 1][8 * (j & 1) + i];
 }
 
+// Operand of a row vector whose magnitude has a STATIC bound (LayerNorm outputs: |(x - mean) rstd| <= sqrt(127), so
+// |y| <= sqrt(127) max|gamma| + max|beta|; sines / cosines; a hidden layer bounded through the L1 norms of its weight rows).
+// The host folds the power-of-two scale `sc` that puts that bound at 2^15 into the parameters that produce the vector
+// (gamma * sc, beta * sc, ...), so `in` arrives already scaled: no row-maximum scan, no scaling multiply — the split is
+// cvt_pkrtz + one subtraction (against the widened hi) + cvt_pkrtz per pair, under half the vector-ALU work of the dynamic form.
+// Precision: the worst-case bound sits a few binades above the typical row maximum, which only lowers the absolute floor
+// of the lo plane (f16 subnormals: 2^-25 in scaled units, i.e. <= 2^-35 of the row maximum).  `sc` / `usc` are carried for
+// the generic gemm() (S = sc * matrix scale).
+__device__ __forceinline__ void make_operand_static(Operand<kModeExact> &o, const f32x16 (&in)[4], float, float)
+{
+    make_operand(o, in);
+}
+
+__device__ __forceinline__ void make_operand_static(Operand<kModeBf16> &o, const f32x16 (&in)[4], float, float)
+{
+    make_operand(o, in);
+}
+
+__device__ __forceinline__ void make_operand_static(Operand<kModeSplit> &o, const f32x16 (&in)[4], float sc, float usc)
+{
+    o.sc = sc;
+    o.usc = usc;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int r = 8 * (j & 1) + 2 * p;
+            const float x0 = in[j >> 1][r], x1 = in[j >> 1][r + 1];
+            const half2v hh = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+            const float r0 = x0 - (float)hh[0], r1 = x1 - (float)hh[1];      // exact in fp32
+            const half2v ll = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
+            o.hi[j][2 * p] = hh[0]; o.hi[j][2 * p + 1] = hh[1];
+            o.lo[j][2 * p] = ll[0]; o.lo[j][2 * p + 1] = ll[1];
+        }
+}
+
 template <int WAVES, int MODE>
 __device__ __forceinline__ void stage_piece(const float *__restrict__ next, f32x4 *next_dst, int wave, int lane, int i)
 {
@@ -235,8 +271,8 @@ __device__ __forceinline__ void gemm_split_core(f32x16 (&acc)[4], const Operand<
     constexpr int kPieces = (kMatVec4 / 64) / WAVES;
     constexpr int kEvery = 32 / kPieces > 0 ? 32 / kPieces : 1;
     constexpr int kPerSlot = kPieces > 32 ? kPieces / 32 : 1;
-    const float S = in.sc * mscale[0], U = in.usc * mscale[1];
     if constexpr (SCALE) {
+        const float S = in.sc * mscale[0];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] *= S;
     }
@@ -276,6 +312,7 @@ __device__ __forceinline__ void gemm_split_core(f32x16 (&acc)[4], const Operand<
     __builtin_amdgcn_s_setprio(0);
 #endif
     if constexpr (SCALE) {
+        const float U = in.usc * mscale[1];
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc[t] *= U;
     }
@@ -361,6 +398,31 @@ __device__ __forceinline__ void gemm_add(f32x16 (&acc)[4], const Operand<MODE> &
             }
         gemm<WAVES>(acc, in, w, mscale, lane, next, next_dst, wave);
     }
+}
+
+// acc += W in with the accumulators LEFT in the operands' scale (split mode; the other modes have no scale): a sum over
+// several GEMMs whose (operand scale x matrix scale) products the host made equal needs no vector-ALU work between them —
+// the caller applies `acc * U + bias` once at the end.
+template <int WAVES, int MODE>
+__device__ __forceinline__ void gemm_raw(f32x16 (&acc)[4], const Operand<MODE> &in, const f32x4 *w, int lane,
+                                         const float *__restrict__ next = nullptr, f32x4 *next_dst = nullptr, int wave = 0)
+{
+    if constexpr (MODE == kModeSplit) gemm_split_core<WAVES, false>(acc, in, w, nullptr, lane, next, next_dst, wave);
+    else gemm<WAVES>(acc, in, w, nullptr, lane, next, next_dst, wave);
+}
+
+// acc = acc * u + add(t, q): the way back from the operands' scale fused with the bias / rank-1 term (one fma per element)
+template <typename Add>
+__device__ __forceinline__ void scale_add(f32x16 (&acc)[4], float u, Add add)
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 a = add(t, q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][4 * q + j] = fmaf(acc[t][4 * q + j], u, a[j]);
+        }
 }
 
 // the additive term of gemm_add for a per-feature vector (bias) in LDS / global memory; nullptr: zero
@@ -599,21 +661,22 @@ template <bool AFFINE, bool RELU>
 __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restrict__ gamma,
                                            const float *__restrict__ beta, int h, float eps)
 {
+    // partial sums over the registers r = k mod 4, in the order (t, r): the order of the stepped form in chain_pair.hip.h
     float s[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) s[t] += v[t][r];
+        for (int r = 0; r < 16; ++r) s[r & 3] += v[t][r];
     float sum = (s[0] + s[1]) + (s[2] + s[3]);
     sum += xhalf(sum);
     const float mean = sum * (1.0f / kC);
     float q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int r = 0; r < 16; ++r) {
             v[t][r] -= mean;
-            q[t] = fmaf(v[t][r], v[t][r], q[t]);
+            q[r & 3] = fmaf(v[t][r], v[t][r], q[r & 3]);
         }
     float sq = (q[0] + q[1]) + (q[2] + q[3]);
     sq += xhalf(sq);
@@ -635,6 +698,35 @@ __device__ __forceinline__ void layer_norm(f32x16 (&v)[4], const float *__restri
             for (int j = 0; j < 4; ++j) {
                 float y = v[t][4 * qd + j] * rstd;
                 if (AFFINE) y = fmaf(y, g[j], b[j]);
+                v[t][4 * qd + j] = RELU ? fmaxf(y, 0.f) : y;
+            }
+        }
+}
+
+// LayerNorm of a row whose mean is ZERO by construction: the host centred the Linear layer that produced it (rows of
+// (I - 11^T / 128) W, centred bias and rank-1 column — the mean of W f + b is linear in f), so the mean pass and the
+// subtraction disappear.  gamma / beta arrive pre-multiplied by the static operand scale of the consumer.
+template <bool RELU>
+__device__ __forceinline__ void layer_norm_centered(f32x16 (&v)[4], const float *__restrict__ gamma,
+                                                    const float *__restrict__ beta, int h, float eps)
+{
+    float q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) q[r & 3] = fmaf(v[t][r], v[t][r], q[r & 3]);
+    float sq = (q[0] + q[1]) + (q[2] + q[3]);
+    sq += xhalf(sq);
+    const float rstd = rsqrtf(sq * (1.0f / kC) + eps);
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(gamma + 32 * t + 8 * qd + 4 * h);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(beta + 32 * t + 8 * qd + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float y = fmaf(v[t][4 * qd + j] * rstd, g[j], b[j]);
                 v[t][4 * qd + j] = RELU ? fmaxf(y, 0.f) : y;
             }
         }

@@ -12,33 +12,50 @@
 // input column (x itself) is a rank-1 term folded into the accumulator init.  LDS holds only the double-buffered
 // packed weights.  MFMA-bound: 2*128*(129+128) flops per row and input dim + 2*128*128 for to_out.
 #include "chain_tile.hip.h"
+#include <cstdio>
 
 namespace {
 
 using namespace qcn_chain;
 
-// packed parameter layout (floats); host side: FourierEmbedding.packed_weights
-//   matrices (chain-packed, 16384 each): [W1_0, W2_0, W1_1, W2_1, ..., Wout]
-//   then per input dim: freq[64], w1_last[128], b1, ln_g, ln_b, b2            (kDimVecs floats)
-//   then to_out: ln_g, ln_b, b                                               (3 * 128)
-//   then {scale, 1 / scale} per matrix                                       (32 floats reserved)
-constexpr int kVFreq = 0, kVW1Last = 64, kVB1 = 64 + kC, kVG1 = 64 + 2 * kC, kVBe1 = 64 + 3 * kC, kVB2 = 64 + 4 * kC,
-              kDimVecs = 64 + 5 * kC;
-constexpr int kVOutG = 0, kVOutBe = kC, kVOutB = 2 * kC, kOutVecs = 3 * kC, kScales = 32;
+// packed parameter layout (floats); host side: ops.pack_fourier (include/qcnet_hip.h, qcn_fourier_embed_f32)
+//   matrices (chain-packed, 16384 each): [W1c_0, W2_0, W1c_1, W2_1, ..., Wout]   (W1c: output-centred first layers)
+//   then per input dim: freq[64], w1c_last[128], b1c, ln_g * s1, ln_b * s1, {max|freq[0:32]|, max|freq[32:64]|, 0, 0}  (kDimVecs)
+//   then to_out: sum_d b2_d, ln_g * so, ln_b * so, b                            (kOutVecs)
+//   then the scale table (32 floats): U_m = 1 / (operand scale x matrix scale) for the first layers m = 2 d and
+//   to_out m = 2 IN, [24] = so, [25] = 1 / so, [26] = U of the W2_d (one value)
+// s1 / so: static power-of-two operand scales of the LayerNorm outputs (chain_tile.hip.h make_operand_static); the W2_d
+// are packed so that s1_d x (matrix scale of W2_d) is the same for every d: their products accumulate in ONE scale.
+constexpr int kVFreq = 0, kVW1Last = 64, kVB1 = 64 + kC, kVG1 = 64 + 2 * kC, kVBe1 = 64 + 3 * kC, kVFmx = 64 + 4 * kC,
+              kDimVecs = 64 + 4 * kC + 4;
+constexpr int kVB2 = 0, kVOutG = kC, kVOutBe = 2 * kC, kVOutB = 3 * kC, kOutVecs = 4 * kC, kScales = 32, kTblSo = 24, kTblU2 = 26;
 
-// sin and cos of an fp32 angle in radians: three-term Cody-Waite reduction by 2 pi (fma, so every step is exact up to the
-// final rounding of the remainder) and the revolution-based hardware v_sin_f32 / v_cos_f32.  Max abs error against the
-// exact sin / cos of the same fp32 angle: 3.7e-7 for |angle| < 6000 (ocml sincosf: 7e-8; scripts/dbg/sincos_acc.hip) at a
-// quarter of its instruction count.
+// The reference's angle ((x * f) * 2) * pi, evaluated in fp32 in that order (layers/fourier_embedding.py:58): the doubling is
+// exact, so the two last products are ONE rounding of p * (2 pi_f32) with p = fl(x * f).
+__device__ __forceinline__ float fourier_angle(float xv, float f, float *p_out)
+{
+    const float p = __fmul_rn(xv, f);
+    *p_out = p;
+    return __fmul_rn(p, 6.2831854820251465f);    // 2 * 3.1415927410125732 (pi rounded to fp32), exactly representable
+}
+
+// sin and cos of that fp32 angle: three-term Cody-Waite reduction by 2 pi (fma, so every step is exact up to the final
+// rounding of the remainder) and the revolution-based hardware v_sin_f32 / v_cos_f32.  The multiple k of 2 pi is rint(p)
+// — p is the angle in revolutions up to 1e-7 relative, so the remainder stays within +-(pi + 1e-3) — which takes the
+// rounding of k off the dependency chain p -> angle -> remainder -> sin (one wave per SIMD runs this chain unhidden).
+// Max abs error against the exact sin / cos of the same fp32 angle: 3.7e-7 for |angle| < 6000 (ocml sincosf: 7e-8;
+// scripts/dbg/sincos_acc.hip) at a quarter of its instruction count.
 // Valid for |ang| <= 2^15 (the caller takes the ocml path for a lane's whole input dim otherwise, see fourier_kernel).
-__device__ __forceinline__ void sincos_2pi(float ang, float *sn, float *cs)
+__device__ __forceinline__ void fourier_sincos(float xv, float f, float *sn, float *cs)
 {
     const float inv2pi = 0.15915494309189535f;
-    const float k = rintf(ang * inv2pi);
-    float f = fmaf(-k, 6.28125f, ang);                       // 2 pi = 6.28125 + 1.9350051879882812e-3 + 3.0199159795e-7
-    f = fmaf(-k, 1.9350051879882812e-3f, f);
-    f = fmaf(-k, 3.0199159795074593e-7f, f);
-    const float rev = f * inv2pi;
+    float p;
+    const float ang = fourier_angle(xv, f, &p);
+    const float k = rintf(p);
+    float r = fmaf(-k, 6.28125f, ang);                       // 2 pi = 6.28125 + 1.9350051879882812e-3 + 3.0199159795e-7
+    r = fmaf(-k, 1.9350051879882812e-3f, r);
+    r = fmaf(-k, 3.0199159795074593e-7f, r);
+    const float rev = r * inv2pi;
     *sn = __builtin_amdgcn_sinf(rev);
     *cs = __builtin_amdgcn_cosf(rev);
 }
@@ -103,10 +120,8 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int s = 4 * q + j;
-                // ((x * f) * 2) * pi in fp32, the reference's evaluation order (:58)
-                const float ang = __fmul_rn(__fmul_rn(__fmul_rn(xv, f4[j]), 2.0f), 3.14159265358979323846f);
                 float sn, cs;
-                sincos_2pi(ang, &sn, &cs);
+                fourier_sincos(xv, f4[j], &sn, &cs);
                 ft[s >> 4][s & 15] = cs;
                 ft[2 + (s >> 4)][s & 15] = sn;
             }
@@ -118,47 +133,39 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int s = 4 * q + j;
-                    const float ang = __fmul_rn(__fmul_rn(__fmul_rn(xv, f4[j]), 2.0f), 3.14159265358979323846f);
-                    float sn, cs;
-                    sincosf(ang, &sn, &cs);
+                    float sn, cs, p;
+                    sincosf(fourier_angle(xv, f4[j], &p), &sn, &cs);
                     ft[s >> 4][s & 15] = cs;
                     ft[2 + (s >> 4)][s & 15] = sn;
                 }
             }
         }
-        // ---- h = W1 [features, x] + b1 : the 129th input column is a rank-1 term folded into the accumulator init
+        // ---- h = W1 [features, x] + b1, centred (the host centred W1 / b1 over the output features): sines and cosines
+        // are a static-scale operand (|.| <= 1), the 129th input column (x itself) is a rank-1 term that joins the bias in
+        // the one fma that also brings the accumulators back from the operands' scale
+        make_operand_static(op, ft, 1.0f, 1.0f);
         f32x16 acc_h[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dv + kVB1 + 32 * t + 8 * q + 4 * h);
-                const f32x4 wl = *reinterpret_cast<const f32x4 *>(dv + kVW1Last + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc_h[t][4 * q + j] = fmaf(xv, wl[j], b1[j]);
-            }
-        make_operand(op, ft);
+        fill_zero(acc_h);
         sync_for_stage();
-        gemm<WAVES>(acc_h, op, buf0, msc + 4 * d, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
+        gemm_raw<WAVES, MODE>(acc_h, op, buf0, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
         skew_after_gemm(skew);
-        layer_norm<true, true>(acc_h, dv + kVG1, dv + kVBe1, h, eps);
-        // ---- y += W2 h + b2
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 b2 = *reinterpret_cast<const f32x4 *>(dv + kVB2 + 32 * t + 8 * q + 4 * h);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc_y[t][4 * q + j] += b2[j];
-            }
-        make_operand(op, acc_h);
+        scale_add(acc_h, msc[2 * d], [&](int t, int q) {
+            const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dv + kVB1 + 32 * t + 8 * q + 4 * h);
+            const f32x4 wl = *reinterpret_cast<const f32x4 *>(dv + kVW1Last + 32 * t + 8 * q + 4 * h);
+            return f32x4{fmaf(xv, wl[0], b1[0]), fmaf(xv, wl[1], b1[1]), fmaf(xv, wl[2], b1[2]), fmaf(xv, wl[3], b1[3])};
+        });
+        if constexpr (MODE == kModeBf16) layer_norm<true, true>(acc_h, dv + kVG1, dv + kVBe1, h, eps);   // bf16: W1 as it is
+        else layer_norm_centered<true>(acc_h, dv + kVG1, dv + kVBe1, h, eps);
+        // ---- y += W2 h: every input dim accumulates in the same scale, nothing happens between these GEMMs
+        make_operand_static(op, acc_h, 1.0f, 1.0f);
         sync_for_stage();
-        gemm<WAVES>(acc_y, op, buf1, msc + 4 * d + 2, lane,
-                    tail.fold && d == IN - 1 ? tail.wt : mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
+        gemm_raw<WAVES, MODE>(acc_y, op, buf1, lane,
+                              tail.fold && d == IN - 1 ? tail.wt : mats + (size_t)(2 * d + 2) * kMatFloats, buf0, wave);
         skew_after_gemm(skew);
     }
-
-    if (extra != nullptr) {   // summed categorical embeddings (:65-66)
+    // y = U2 acc + sum_d b2_d (+ the summed categorical embeddings, :65-66)
+    scale_add(acc_y, msc[kTblU2], BiasTerm{out_vec + kVB2, h});
+    if (extra != nullptr) {
         f32x16 e[4];
         load_row(e, extra, rowc / extra_div, h);
 #pragma unroll
@@ -167,14 +174,15 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 
     // ---- to_out: LN -> ReLU -> Linear (:67)
     layer_norm<true, true>(acc_y, out_vec + kVOutG, out_vec + kVOutBe, h, eps);
-    make_operand(op, acc_y);
+    make_operand_static(op, acc_y, msc[kTblSo], msc[kTblSo + 1]);
     const int64_t row0 = row - (lane & 31);
     if (!tail.fold) {
         f32x16 acc_o[4];
-        load_feature_vec(acc_o, out_vec + kVOutB, h);
+        fill_zero(acc_o);
         sync_for_stage();
-        gemm<WAVES>(acc_o, op, buf0, msc + 4 * IN, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
+        gemm_raw<WAVES, MODE>(acc_o, op, buf0, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
         skew_after_gemm(skew);
+        scale_add(acc_o, msc[2 * IN], BiasTerm{out_vec + kVOutB, h});
         if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);
         if (tail.n_out == 0) {
             if (normalize_out == 2) store_tile2_split(acc_o, reinterpret_cast<_Float16 *>(y), row0, n_rows, xpose, lane, 2048.0f);
@@ -206,9 +214,21 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 
 }  // namespace
 
+#include "fourier_pair.hip.h"
+
 extern "C" size_t qcn_fourier_pack_floats(int input_dim)
 {
     return (size_t)(2 * input_dim + 1) * kMatFloats + (size_t)input_dim * kDimVecs + kOutVecs + kScales;
+}
+
+// launches of at least this many rows take the two-tile kernel (QCN_PAIR_MIN_ROWS overrides, for A/B runs)
+static int64_t pair_min_rows()
+{
+    static const int64_t v = [] {
+        const char *env = getenv("QCN_PAIR_MIN_ROWS");
+        return env ? (int64_t)atoll(env) : (int64_t)192 * kPairBlockRows;
+    }();
+    return v;
 }
 
 static int launch_fourier(const float *x, int input_dim, const float *extra, int64_t extra_div, const float *pack,
@@ -220,12 +240,92 @@ static int launch_fourier(const float *x, int input_dim, const float *extra, int
     if (!pack || (tail.n_out == 0 && !y) || (input_dim > 0 && !x) || (input_dim == 0 && !extra)) return QCN_ERR_INVALID_ARGUMENT;
     if (extra_div < 1 || extra_div > 0x7fffffff || normalize_out < 0 || normalize_out > 3) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
+    // Two tiles per wave (fourier_pair.hip.h) for the launches that fill the chip and whose rows carry three or four input
+    // dims; the one-tile kernel below keeps the small launches (its 2- and 4-wave blocks spread few rows over more CUs), the
+    // exact mode, input_dim < 3, categorical embeddings and the tail forms (measured, 800 k rows, split mode, same box:
+    // input_dim 3 / 4 take 0.90-0.93 of the one-tile kernel's time, input_dim 2 takes 1.1, the folded tail the same time —
+    // its three outputs are bound by their stores).  QCN_PAIR_TAIL=1 builds the tail / input_dim 2 instantiations for A/B runs.
+#ifdef QCN_PAIR_TAIL
+    const bool pair_ok = input_dim >= 2 && (tail.n_out == 0 || tail.fold);
+#else
+    const bool pair_ok = input_dim >= 3 && tail.n_out == 0;
+#endif
+    if (mode != QCN_MATMUL_EXACT_F32 && extra == nullptr && pair_ok && n_rows >= pair_min_rows()) {
+        const unsigned pgrid = (unsigned)((n_rows + kPairBlockRows - 1) / kPairBlockRows);
+#define QCN_PAIR(IN_, M_, T_, N_)                                                                                         \
+    hipLaunchKernelGGL((fourier_pair_kernel<IN_, M_, T_, N_>), dim3(pgrid), dim3(64 * kPairWaves), 0, s, x, pack, y, n_rows, tail)
+#ifdef QCN_PAIR_TAIL
+#define QCN_PAIR_T(IN_, M_) if (tail.n_out > 0) QCN_PAIR(IN_, M_, true, 0); else
+#else
+#define QCN_PAIR_T(IN_, M_)
+#endif
+#define QCN_PAIR_N(IN_, M_)                                                          \
+    do {                                                                             \
+        QCN_PAIR_T(IN_, M_)                                                          \
+        if (normalize_out == 0) QCN_PAIR(IN_, M_, false, 0);                         \
+        else if (normalize_out == 1) QCN_PAIR(IN_, M_, false, 1);                    \
+        else if (normalize_out == 2) QCN_PAIR(IN_, M_, false, 2);                    \
+        else QCN_PAIR(IN_, M_, false, 3);                                            \
+    } while (0)
+#define QCN_PAIR_M(IN_)                                                              \
+    do {                                                                             \
+        if (mode == QCN_MATMUL_SPLIT_F16) QCN_PAIR_N(IN_, QCN_MATMUL_SPLIT_F16);     \
+        else QCN_PAIR_N(IN_, QCN_MATMUL_BF16);                                       \
+    } while (0)
+#ifdef QCN_EXP_ONLY
+        QCN_PAIR(3, QCN_MATMUL_SPLIT_F16, false, 1);
+#else
+#ifdef QCN_PAIR_TAIL
+        if (input_dim == 2) QCN_PAIR_M(2);
+        else
+#endif
+        if (input_dim == 3) QCN_PAIR_M(3);
+        else QCN_PAIR_M(4);
+#endif
+#undef QCN_PAIR_M
+#undef QCN_PAIR_N
+#undef QCN_PAIR_T
+#undef QCN_PAIR
+#ifdef QCN_SLOT_STAMPS
+        {
+            unsigned long long hst[kPairWaves][32];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_slot_stamps), sizeof(hst));
+            for (int w = 0; w < kPairWaves; ++w) {
+                printf("slot stamps in=%d wave %d:", input_dim, w);
+                for (int i = 1; i < 32; ++i) printf(" %llu", hst[w][i] - hst[w][i - 1]);
+                printf("\n");
+            }
+        }
+#endif
+#ifdef QCN_PAIR_STAMPS
+        {
+            unsigned long long hst[kPairWaves][64];
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpyFromSymbol(hst, HIP_SYMBOL(g_pair_stamps), sizeof(hst));
+            for (int w = 0; w < kPairWaves; ++w) {
+                printf("pair stamps in=%d wave %d:", input_dim, w);
+                for (int i = 1; i < 64 && hst[w][i] > hst[w][i - 1]; ++i) printf(" %llu", hst[w][i] - hst[w][i - 1]);
+                printf("\n");
+            }
+        }
+#endif
+        return hipGetLastError() == hipSuccess ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
+    }
     const int waves = pick_waves(n_rows, 1.5);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
 #define QCN_LAUNCH(S, W)                                                                                           \
     hipLaunchKernelGGL((fourier_kernel<QCN_IN, S, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, \
                        n_rows, normalize_out, tail, skew_mode)
+#ifdef QCN_EXP_ONLY   // compile-time experiments: one instantiation per mode
+    hipLaunchKernelGGL((fourier_kernel<3, QCN_MATMUL_SPLIT_F16, 8>), dim3(grid), dim3(512), 0, s, x, extra, (int)extra_div, pack, y,
+                       n_rows, normalize_out, tail, skew_mode);
+    hipLaunchKernelGGL((fourier_kernel<3, QCN_MATMUL_BF16, 8>), dim3(grid), dim3(512), 0, s, x, extra, (int)extra_div, pack, y,
+                       n_rows, normalize_out, tail, skew_mode);
+    if (false)
+#endif
+#ifndef QCN_EXP_ONLY
     switch (input_dim) {
 #define QCN_IN 0
     case 0: QCN_CHAIN_DISPATCH(mode, waves); break;
@@ -243,6 +343,9 @@ static int launch_fourier(const float *x, int input_dim, const float *extra, int
     default: QCN_CHAIN_DISPATCH(mode, waves); break;
 #undef QCN_IN
     }
+#else
+    {}
+#endif
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;
     return ok ? QCN_OK : QCN_ERR_LAUNCH_FAILED;

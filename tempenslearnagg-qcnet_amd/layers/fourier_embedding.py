@@ -48,26 +48,11 @@ class FourierEmbedding(nn.Module):
         mode = ops.matmul_mode()
         key = (mode,) + tuple((p.data_ptr(), p._version) for p in params)
         if key != self._pack_key:
-            mats, orders, vecs = [], [], []
             with torch.no_grad():
-                nf = 2 * self.num_freq_bands
-                # k-step s of the first layer takes, from lane half h, cos (s < 32) or sin (s >= 32) of frequency
-                # 32 h + (s mod 32): input column 32 h + s resp. 64 + 32 h + (s - 32) of the reference's cat order
-                s_idx = torch.arange(64).unsqueeze(1)
-                h_idx = torch.arange(2).unsqueeze(0)
-                first_layer_order = torch.where(s_idx < 32, 32 * h_idx + s_idx, 64 + 32 * h_idx + (s_idx - 32))
-                for i in range(self.input_dim):
-                    lin1, ln, _, lin2 = self.mlps[i]
-                    mats += [lin1.weight[:, :nf], lin2.weight]
-                    orders += [first_layer_order, None]
-                    vecs += [self.freqs.weight[i], lin1.weight[:, nf], lin1.bias, ln.weight, ln.bias, lin2.bias]
+                mlps = [(m[0].weight, m[0].bias, m[1].weight, m[1].bias, m[3].weight, m[3].bias) for m in self.mlps]
                 ln, _, lin = self.to_out
-                mats.append(lin.weight)
-                orders.append(None)
-                vecs += [ln.weight, ln.bias, lin.bias]
-                packed, scales = ops.pack_chain_set(mats, orders, mode=mode)
-                self._pack = torch.cat([packed.reshape(-1)] + [p.reshape(-1).float() for p in vecs]
-                                       + [ops.scale_table(scales)]).contiguous()
+                self._pack = ops.pack_fourier(self.freqs.weight if self.freqs is not None else None, mlps,
+                                              (ln.weight, ln.bias, lin.weight, lin.bias), mode=mode)
             self._pack_key = key
         return self._pack
 

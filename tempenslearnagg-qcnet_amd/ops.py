@@ -289,12 +289,39 @@ def _mode(mode: Optional[int]) -> int:
     return mode
 
 
+def split_matrix_scale(weight: torch.Tensor) -> float:
+    """The power of two that puts max|W| into [2^14, 2^15) (1.0 for a zero matrix): the split mode's matrix scale."""
+    m = float(weight.detach().abs().max())
+    if not m > 0:
+        return 1.0
+    _, e = torch.frexp(torch.tensor(m))                 # m = f * 2^e, f in [1/2, 1)
+    return 2.0 ** (15 - int(e))
+
+
+def static_operand_scale(bound: float) -> float:
+    """Power-of-two operand scale for a row vector with |x| <= ``bound`` (csrc/chain_tile.hip.h make_operand_static):
+    bound * scale lands in (2^14, 2^15], a factor two below the f16 overflow threshold."""
+    if not bound > 0:
+        return 1.0
+    _, e = torch.frexp(torch.tensor(float(bound)))      # bound <= 2^e
+    return 2.0 ** (15 - int(e))
+
+
+LN_MAX_ABS = 127.0 ** 0.5   # |(x - mean) / sqrt(var + eps)| <= sqrt(n - 1) for n = 128 features
+
+
+def layer_norm_bound(ln_weight: torch.Tensor, ln_bias: torch.Tensor) -> float:
+    """Rigorous bound on |LayerNorm(x)| over all inputs: sqrt(127) max|gamma| + max|beta| (1 % slack for rounding)."""
+    return 1.01 * (LN_MAX_ABS * float(ln_weight.detach().abs().max()) + float(ln_bias.detach().abs().max()))
+
+
 def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = None,
-                      mode: Optional[int] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+                      mode: Optional[int] = None, scale: Optional[float] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """A ``nn.Linear(128, 128).weight`` ([out, in]) in the order the chain kernels consume it, for the matmul mode in
     force: (16384 floats, {scale, 1 / scale}) — layouts in include/qcnet_hip.h, 'Chain-packed 128x128 matrix'.
     ``in_index`` [64, 2]: the input column that register position s of lane half h stands for; defaults to
-    :func:`chain_feature_order` (the operand is a register-resident row vector)."""
+    :func:`chain_feature_order` (the operand is a register-resident row vector).  ``scale`` (split mode): a power of two
+    not above :func:`split_matrix_scale` to use instead of it (sums of GEMMs that share one accumulator scale)."""
     if tuple(weight.shape) != (C, C):
         raise ValueError('pack_chain_matrix expects a [128, 128] weight, got %s' % (tuple(weight.shape),))
     mode = _mode(mode)
@@ -321,10 +348,12 @@ def pack_chain_matrix(weight: torch.Tensor, in_index: Optional[torch.Tensor] = N
         return packed.contiguous(), torch.ones(2, dtype=torch.float32, device=dev)
     if mode != MATMUL_SPLIT_F16:
         raise ValueError('unknown matmul mode %r' % (mode,))
-    _, e = torch.frexp(w.abs().max())                   # max|W| = f * 2^e, f in [1/2, 1)
-    e = int(e) if float(w.abs().max()) > 0 else 0
-    scale = 2.0 ** (15 - e)
-    ws = w * scale                                      # exact (power of two); max|ws| in [2^14, 2^15)
+    auto_scale = split_matrix_scale(w)
+    if scale is None:
+        scale = auto_scale
+    elif not 0 < scale <= auto_scale:
+        raise ValueError('pack_chain_matrix: scale %r would overflow the f16 planes (at most %r)' % (scale, auto_scale))
+    ws = w * scale                                      # exact (power of two); max|ws| < 2^15
     hi = ws.half()
     lo = (ws - hi.float()).half()                       # ws - hi is exact in fp32
     kin = in_index.view(8, 8, 2).permute(0, 2, 1)       # [j, h, i] = in_index[8 j + i, h]
@@ -355,6 +384,58 @@ def scale_table(scales: torch.Tensor, size: int = 32) -> torch.Tensor:
     """Scale pairs padded to the fixed-size table at the end of the Fourier / attn_post packs."""
     flat = scales.reshape(-1)
     return torch.cat([flat, flat.new_ones(size - flat.numel())])
+
+
+def pack_fourier(freqs: Optional[torch.Tensor], mlps: Sequence[Sequence[torch.Tensor]], to_out: Sequence[torch.Tensor],
+                 mode: Optional[int] = None) -> torch.Tensor:
+    """The ``pack`` of qcn_fourier_embed_f32 (include/qcnet_hip.h) for one FourierEmbedding (layers/fourier_embedding.py:25-46).
+    ``freqs`` [input_dim, 64] (None for input_dim 0); ``mlps[i]`` = (mlps.i.0.weight [128, 129], mlps.i.0.bias, mlps.i.1.weight,
+    mlps.i.1.bias, mlps.i.3.weight, mlps.i.3.bias); ``to_out`` = (to_out.0.weight, to_out.0.bias, to_out.2.weight, to_out.2.bias).
+
+    Two exact rewrites happen here instead of in the kernel's vector ALU:
+    * the first Linear of every per-dimension MLP is CENTRED over its output features (rows of (I - 11^T / 128) W, centred
+      bias): LayerNorm's mean of W f + b is linear in f, so the kernel's LayerNorm starts at the variance (formed in fp64);
+    * every LayerNorm affine carries the static power-of-two operand scale of the GEMM that consumes it (split mode), and
+      the second Linear layers share ONE accumulator scale, so their sum over input dims needs no work between the GEMMs."""
+    mode = _mode(mode)
+    split = mode == MATMUL_SPLIT_F16
+    input_dim = len(mlps)
+    dev = to_out[2].device
+    f32 = lambda t: t.detach().to(dev, torch.float32)
+    s_idx = torch.arange(64).unsqueeze(1)
+    h_idx = torch.arange(2).unsqueeze(0)
+    # k-step s of a first layer takes, from lane half h, cos (s < 32) or sin (s >= 32) of frequency 32 h + (s mod 32):
+    # input column 32 h + s resp. 64 + 32 h + (s - 32) of the reference's cat order (layers/fourier_embedding.py:59)
+    first_layer_order = torch.where(s_idx < 32, 32 * h_idx + s_idx, 64 + 32 * h_idx + (s_idx - 32))
+    # (not in the bf16 mode: its operands are the bf16 roundings of the reference's own weights, the kernels keep the mean pass)
+    centre = ((lambda t: t) if mode == MATMUL_BF16 else
+              (lambda t: (t.double() - t.double().mean(dim=0, keepdim=True)).float()))   # over the output features
+
+    s1 = [static_operand_scale(layer_norm_bound(m[2], m[3])) if split else 1.0 for m in mlps]
+    so = static_operand_scale(layer_norm_bound(to_out[0], to_out[1])) if split else 1.0
+    # common accumulator scale of the second layers: operand scale x matrix scale, the smallest over the input dims
+    w2_scale = [split_matrix_scale(centre(f32(m[4]))) if split else 1.0 for m in mlps]
+    acc2 = min([a * b for a, b in zip(s1, w2_scale)], default=1.0)
+
+    mats, table, vecs = [], torch.ones(32, dtype=torch.float32, device=dev), []
+    for i, (w1, b1, g, be, w2, b2) in enumerate(mlps):
+        w1c = centre(f32(w1))
+        p1, sc1 = pack_chain_matrix(w1c[:, :C], first_layer_order, mode)
+        p2, _ = pack_chain_matrix(centre(f32(w2)), None, mode, scale=acc2 / s1[i] if split else None)
+        mats += [p1, p2]
+        table[2 * i] = float(sc1[1])                       # sines / cosines: operand scale 1
+        fr = f32(freqs[i])
+        fmx = torch.stack([fr[:32].abs().max(), fr[32:].abs().max(), fr.new_zeros(()), fr.new_zeros(())])
+        vecs += [fr, w1c[:, C].contiguous(), centre(f32(b1)), f32(g) * s1[i], f32(be) * s1[i], fmx]
+    g, be, w, b = to_out
+    p, sc = pack_chain_matrix(f32(w), None, mode)
+    mats.append(p)
+    table[2 * input_dim] = float(sc[1]) / so
+    table[24], table[25], table[26] = so, 1.0 / so, 1.0 / acc2
+    b2_sum = torch.stack([f32(m[5]).double() for m in mlps]).sum(dim=0).float() if input_dim else torch.zeros(C, device=dev)
+    b2_sum = centre(b2_sum)     # second layers centred too: without categorical embeddings to_out's LayerNorm sees zero-mean rows
+    vecs += [b2_sum, f32(g) * so, f32(be) * so, f32(b)]
+    return torch.cat([m.reshape(-1) for m in mats] + [v.reshape(-1) for v in vecs] + [table]).contiguous()
 
 
 def fourier_embed(x: Optional[torch.Tensor], input_dim: int, pack: torch.Tensor, extra: Optional[torch.Tensor] = None,
