@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 from _bootstrap import ensure_package
 ensure_package()
-from tempenslearnagg_qcnet_amd import ops
+from tempenslearnagg_qcnet_amd import ops, _lib
+if os.environ.get("QCN_LIB"):
+    _lib.LIB_PATH = os.path.abspath(os.environ["QCN_LIB"])
 from tempenslearnagg_qcnet_amd.layers import FourierEmbedding
 dev = torch.device('cuda:0')
 m = FourierEmbedding(2, 128, 64).to(dev).eval()
