@@ -314,12 +314,16 @@ class QCNetAgentEncoder(nn.Module):
         t_src, t_dst, t_agent = cache['t_src'], cache['t_dst'], cache['t_agent']
         E_abs = t_src.numel()
         can_src, can_dst = t_src * A + t_agent, t_dst * A + t_agent
+        # the long run's temporal relation is the same in every layer: ONE destination sort; a layer's special destinations
+        # come after the long run's rows and their edge lists are produced already grouped by destination (below), so
+        # they are appended to the CSR without sorting again
+        rp_can, col_can, eid_can = ops.csr_build(torch.stack([can_src, can_dst]), NA)
         layers = []
         for l in range(1, NL + 1):
             Dp, Dl = D[l - 1], D[l]
             n_prev, n_own = (F - 1) * len(Dp) * A, (F - 1) * len(Dl) * A
-            src_all, dst_all, eid_all = [can_src], [can_dst], [torch.arange(E_abs, **i64)]
             own_idx = None
+            rowptr, col, eid = rp_can, col_can, eid_can
             if n_own:
                 # the destinations' own rows (residual / query input): previous-layer value at (f, d)
                 own = []
@@ -343,14 +347,15 @@ class QCNetAgentEncoder(nn.Module):
                 slot = pos_in_prev[dp.clamp(0, T)]
                 is_special = dp <= (l - 1) * S
                 src_special = NA + n_own + ((fj - 1) * max(len(Dp), 1) + slot.clamp_min(0)) * A + ag
-                src_all.append(torch.where(is_special, src_special, t_src[e_sel] * A + ag))
-                dst_all.append(NA + j_sel * A + ag)
-                eid_all.append(e_sel)
+                # (j_sel, e_sel) ascend in (j, edge) order and the cached edges are row-major in (agent, source step), so
+                # the special destinations j * A + agent ascend with sources ascending inside a row: CSR order already
+                first = torch.searchsorted(j_sel * A + ag, torch.arange(n_own + 1, **i64)) + E_abs
+                rowptr = torch.cat([rp_can[:NA], first.to(torch.int32),
+                                    torch.full((n_prev,), E_abs + int(e_sel.numel()), dtype=torch.int32, device=dev)])
+                col = torch.cat([col_can, torch.where(is_special, src_special, t_src[e_sel] * A + ag).to(torch.int32)])
+                eid = torch.cat([eid_can, e_sel.to(torch.int32)])
             n_in = NA + n_own + (n_prev if n_own else 0)
-            g_t = CSRGraph.from_edge_index(torch.stack([torch.cat(src_all), torch.cat(dst_all)]), n_in, n_in,
-                                           validate=False)
-            g_t.eid = torch.cat(eid_all).to(torch.int32)[g_t.eid.long()]
-            g_t.num_feature_rows = cache['r_t'].rhat.size(0)
+            g_t = CSRGraph(None, n_in, n_in, rowptr, col, eid, num_feature_rows=cache['r_t'].rhat.size(0))
 
             # spatial relations over [long run | special rows (f, d, a)]
             if n_own:

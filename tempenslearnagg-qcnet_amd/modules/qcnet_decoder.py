@@ -205,7 +205,7 @@ class QCNetDecoder(nn.Module):
 
             pos_t = agent['position'][:, ts:T + ts, :2].reshape(-1, 2)
             head_t = agent['heading'][:, ts:T + ts].reshape(-1)
-            ei_t2m_1 = mask_outer_edges(mask_src, mask_dst[:, -1:])
+            ei_t2m_1, off_t2m = ops.mask_pairs(mask_src, mask_dst[:, -1:])
             r_t2m = rel_geometry(pos_t, pos_m, head_t, head_m, ei_t2m_1, extra=(ei_t2m_1[0] % T) - T + 1)
             # One positional embedding / edge list per (step, agent) pair; the K mode queries of the agent share it
             # (reference: r_t2m.repeat_interleave(K) and a K-times larger edge list, :169-170).
@@ -214,12 +214,14 @@ class QCNetDecoder(nn.Module):
             # checks only — the kernels work on the base lists — and are built on request (one enumeration launch with a
             # host round trip and two K-fold concatenations per call otherwise)
             ei_t2m = mask_outer_edges(mask_src, mask_dst) if return_edge_index else None
-            g_t2m = CSRGraph.from_edge_index(ei_t2m_1, A * T, A, validate=False)
-            col = g_t2m.col.long()                      # a * T + t  ->  a * Mt + (t - (T - Mt))
+            # the enumeration is row-major over (agent, step): already grouped by destination agent, sources ascending —
+            # the CSR needs no sort, its row pointer is every T-th entry of the enumeration's per-source-row offsets
+            col = ei_t2m_1[0]                           # a * T + t  ->  a * Mt + (t - (T - Mt))
             col = col - (torch.div(col, T, rounding_mode='floor') + 1) * (T - Mt)
             if t_index is not None:
                 col = t_index.reshape(-1)[col]
-            g_t2m = g_t2m.remap_sources(col, n_t_rows).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
+            g_t2m = CSRGraph(ei_t2m_1, n_t_rows, A, off_t2m[::T].to(torch.int32), col.to(torch.int32), None)
+            g_t2m = g_t2m.replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_t2m)
 
             pos_pl = data['map_polygon']['position'][:, :2].contiguous()
             orient_pl = data['map_polygon']['orientation'].contiguous()
@@ -244,8 +246,10 @@ class QCNetDecoder(nn.Module):
             ei_a2m = torch.cat([ei_a2m_1 + i * A for i in range(K)], dim=1) if return_edge_index else None
             g_a2m = CSRGraph.from_sorted(ei_a2m_1, off_a2m, A, A).replicate(K, ops.LAYOUT_AGENT_MAJOR, edge_index=ei_a2m)
 
-            ei_m2m = mask_outer_edges(mask_dst, mask_dst)
-            g_m2m = CSRGraph.from_edge_index(ei_m2m, A * K, A * K, validate=False)
+            # mode<->mode edges: a full K x K block per predicted agent, row-major — the relation is symmetric, so the
+            # enumeration read with its rows swapped IS the destination-sorted list (sources ascending): no sort
+            ei_m2m, off_m2m = ops.mask_pairs(mask_dst, mask_dst)
+            g_m2m = CSRGraph(ei_m2m, A * K, A * K, off_m2m.to(torch.int32), ei_m2m[1].to(torch.int32), None)
             for r in (r_t2m, r_pl2m, r_a2m):
                 r.prepare_for(K)
             return (r_t2m, r_pl2m, r_a2m, g_t2m, g_pl2m, g_a2m, g_m2m, ei_pl2m_1, ei_t2m, ei_pl2m, ei_a2m, ei_m2m)
