@@ -220,7 +220,7 @@ def main() -> None:
     # above the attention kernels share the CUs with the next batch's preparation kernels, which lengthens their
     # individual durations while shortening the step; this pass times them alone on the GPU (kernel quality).
     from tempenslearnagg_qcnet_amd.utils import prep as _prep
-    iso = None
+    iso = iso_f = iso_g = None
     data, ids = batches[0], step_ids[0]
     if _prep.ENABLED and not args.no_isolated_pass:
         _prep.ENABLED = False
@@ -233,6 +233,15 @@ def main() -> None:
             torch.cuda.synchronize()
             ops.prof_enable(False)
         iso = ops.prof_collect(ops.PROF_ATTN_FUSED)
+        ops.prof_collect(-1)
+        # ... and the MFMA chain kernels the same way (alone on the GPU, one stream)
+        with torch.no_grad(), torch.cuda.stream(main_stream):
+            ops.prof_enable(True, kinds=[ops.PROF_FOURIER, ops.PROF_GEMM])
+            for _ in range(min(args.steps, 3)):
+                model.predict(data)
+            torch.cuda.synchronize()
+            ops.prof_enable(False)
+        iso_f, iso_g = ops.prof_collect(ops.PROF_FOURIER), ops.prof_collect(ops.PROF_GEMM)
         ops.prof_collect(-1)
         _prep.ENABLED = True
 
@@ -319,6 +328,14 @@ def main() -> None:
                      'launches': f_launches + g_launches, 'steps': n_chain, 'ms_per_step': chain_ms / max(n_chain, 1),
                      'fourier': {'ms_per_step': f_ms / max(n_chain, 1), 'tflops': f_flop / (f_ms * 1e-3) / 1e12 if f_ms > 0 else 0.0},
                      'node': {'ms_per_step': g_ms / max(n_chain, 1), 'tflops': g_flop / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0},
+                     'isolated': None if iso_f is None or iso_f[1] + iso_g[1] <= 0 else
+                     {'achieved': (iso_f[2] + iso_g[2]) / ((iso_f[1] + iso_g[1]) * 1e-3) / 1e12,
+                      'frac': (iso_f[2] + iso_g[2]) / ((iso_f[1] + iso_g[1]) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[mode],
+                      'launches': iso_f[0] + iso_g[0],
+                      'fourier_tflops': iso_f[2] / (iso_f[1] * 1e-3) / 1e12 if iso_f[1] > 0 else 0.0,
+                      'node_tflops': iso_g[2] / (iso_g[1] * 1e-3) / 1e12 if iso_g[1] > 0 else 0.0,
+                      'note': 'the same launches with the preparation stream off: in the timed regime the Fourier launches of the '
+                              'next batch run on the side stream beside the attention kernels, which lengthens both'},
                      'formula': 'fp32-equivalent flop 2*128*128 per row and Linear (SURVEY 8(d)) / summed launch durations (events on '
                                 'the launch stream, in a pass of `steps` steps right after the timed region, same regime); peak = dense MFMA peak of the mode: 157 exact fp32, 2517 / 3 split-f16 '
                                 '(three MFMAs per product), 2517 bf16'},

@@ -40,6 +40,22 @@ class NormalizedEdgeFeatures:
         else:
             self.rhat = rhat
 
+    @classmethod
+    def deferred(cls, make, inputs=(), rep: Optional[int] = None) -> 'NormalizedEdgeFeatures':
+        """The features ``make()`` returns (one large Fourier-embedding launch over tensors ``inputs``), produced where
+        utils/prep.py::defer puts heavy launches: at once outside a preparation section, on the main stream right after
+        the section inside one.  ``rep``: convert for a relation with that many queries per row (prepare_for)."""
+        from ..utils import prep
+        self = cls.__new__(cls)
+        self.rhat = self._split = self._bf16 = None
+
+        def fill():
+            cls.__init__(self, make())
+            if rep is not None:
+                self.prepare_for(rep)
+        prep.defer(fill, inputs)
+        return self
+
     @property
     def num_rows(self) -> int:
         return int(next(t for t in (self.rhat, self._split, self._bf16) if t is not None).size(0))

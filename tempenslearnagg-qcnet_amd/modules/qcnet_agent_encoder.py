@@ -103,16 +103,16 @@ class QCNetAgentEncoder(nn.Module):
 
         ei_pl2a, off_pl2a = ops.radius_pairs(pos_s, pos_pl_rep, self.pl2a_radius, ptr_s, ptr_pl, 300, mask_x=mask_s)
         g_pl2a = CSRGraph.from_edge_index(ei_pl2a, n_steps * P, n_steps * A, validate=False).fold_sources(P)
-        r_pl2a = NormalizedEdgeFeatures(self.r_pl2a_emb(
-            continuous_inputs=rel_geometry(pos_pl_rep, pos_s, orient_pl_rep, head_s, ei_pl2a), categorical_embs=None,
-            normalized_output=True))
+        geo_pl2a = rel_geometry(pos_pl_rep, pos_s, orient_pl_rep, head_s, ei_pl2a)
+        r_pl2a = NormalizedEdgeFeatures.deferred(lambda: self.r_pl2a_emb(
+            continuous_inputs=geo_pl2a, categorical_embs=None, normalized_output=True), (geo_pl2a,))
 
         ei_a2a, off_a2a = ops.radius_pairs(pos_s, pos_s, self.a2a_radius, ptr_s, ptr_s, 300 + 1, drop_self=True,
                                            mask_x=mask_s, mask_y=mask_s, y_first=False)
         g_a2a = CSRGraph.from_sorted(ei_a2a, off_a2a, n_steps * A, n_steps * A)
-        r_a2a = NormalizedEdgeFeatures(self.r_a2a_emb(
-            continuous_inputs=rel_geometry(pos_s, pos_s, head_s, head_s, ei_a2a), categorical_embs=None,
-            normalized_output=True))
+        geo_a2a = rel_geometry(pos_s, pos_s, head_s, head_s, ei_a2a)
+        r_a2a = NormalizedEdgeFeatures.deferred(lambda: self.r_a2a_emb(
+            continuous_inputs=geo_a2a, categorical_embs=None, normalized_output=True), (geo_a2a,))
         return dict(g_pl2a=g_pl2a, r_pl2a=r_pl2a, off_pl2a=off_pl2a, g_a2a=g_a2a, r_a2a=r_a2a, off_a2a=off_a2a)
 
     def _layers(self, x_a, x_pl, g_t, r_t, g_pl2a, r_pl2a, g_a2a, r_a2a) -> torch.Tensor:
@@ -163,9 +163,9 @@ class QCNetAgentEncoder(nn.Module):
 
         ei_t = self._temporal_edges(mask)                                    # node id a * n_abs + u
         pos_t, head_t = pos.reshape(-1, 2), head.reshape(-1)
-        r_t = NormalizedEdgeFeatures(self.r_t_emb(
-            continuous_inputs=rel_geometry(pos_t, pos_t, head_t, head_t, ei_t, extra=ei_t[0] - ei_t[1]),
-            categorical_embs=None, normalized_output=True))
+        geo_t = rel_geometry(pos_t, pos_t, head_t, head_t, ei_t, extra=ei_t[0] - ei_t[1])
+        r_t = NormalizedEdgeFeatures.deferred(lambda: self.r_t_emb(
+            continuous_inputs=geo_t, categorical_embs=None, normalized_output=True), (geo_t,))
         agent_of_edge = torch.div(ei_t[0], n_abs, rounding_mode='floor')
         cache = dict(first_shift=s0, n_frames=n_frames, n_abs=n_abs, x_main=x_main, x_first=x_first, r_t=r_t,
                      t_agent=agent_of_edge, t_src=ei_t[0] - agent_of_edge * n_abs, t_dst=ei_t[1] - agent_of_edge * n_abs)
@@ -186,7 +186,7 @@ class QCNetAgentEncoder(nn.Module):
         ei_t = torch.stack([base + cache['t_src'][sel], base + cache['t_dst'][sel]], dim=0)
         g_t = CSRGraph.from_edge_index(ei_t, A * T, A * T, validate=False)
         g_t.eid = sel.to(torch.int32)[g_t.eid.long()]
-        g_t.num_feature_rows = cache['r_t'].rhat.size(0)
+        g_t.num_feature_rows = int(cache['t_src'].numel())
 
         g_pl2a = cache['g_pl2a'].window(u0 * A, (u0 + T) * A, n_src=P)
         g_a2a = cache['g_a2a'].window(u0 * A, (u0 + T) * A, n_src=T * A, col_shift=u0 * A)
@@ -223,7 +223,7 @@ class QCNetAgentEncoder(nn.Module):
         ei_t = torch.stack([base + cache['t_src'][e_sel], base + cache['t_dst'][e_sel]], dim=0)
         g_t = CSRGraph.from_edge_index(ei_t, F * A * T, F * A * T, validate=False)
         g_t.eid = e_sel.to(torch.int32)[g_t.eid.long()]
-        g_t.num_feature_rows = cache['r_t'].rhat.size(0)
+        g_t.num_feature_rows = int(cache['t_src'].numel())
 
         g_pl2a = cache['g_pl2a'].frames(F, T * A, A, n_src=P)
         g_a2a = cache['g_a2a'].frames(F, T * A, A, n_src=F * T * A, col_shift=A, src_stride=T * A)
@@ -355,7 +355,7 @@ class QCNetAgentEncoder(nn.Module):
                 col = torch.cat([col_can, torch.where(is_special, src_special, t_src[e_sel] * A + ag).to(torch.int32)])
                 eid = torch.cat([eid_can, e_sel.to(torch.int32)])
             n_in = NA + n_own + (n_prev if n_own else 0)
-            g_t = CSRGraph(None, n_in, n_in, rowptr, col, eid, num_feature_rows=cache['r_t'].rhat.size(0))
+            g_t = CSRGraph(None, n_in, n_in, rowptr, col, eid, num_feature_rows=int(cache['t_src'].numel()))
 
             # spatial relations over [long run | special rows (f, d, a)]
             if n_own:

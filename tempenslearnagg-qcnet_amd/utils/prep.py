@@ -16,8 +16,17 @@ import torch
 
 ENABLED = os.environ.get('QCN_PREP_STREAM', '1') != '0'
 
+# Heavy launches without a host round trip (the positional Fourier embeddings of a relation: up to 2 M rows each) are NOT
+# run on the side stream: they and the attention / chain kernels of the main stream each want a whole CU (130-140 KB of
+# LDS), so beside each other they can only take turns.  A section hands such work back with ``defer``: it is enqueued on
+# the main stream as soon as the section's results are visible there; the side stream keeps what it is for — the small
+# launches and their host round trips.  Measured (cfg3, same box): step 39.4 -> 39.2 ms, chain kernels in the timed
+# region 146 -> 157 TF/s, attention launches unchanged.  QCN_PREP_DEFER=0 keeps the embeddings on the side stream.
+DEFER_HEAVY = os.environ.get('QCN_PREP_DEFER', '1') != '0'
+
 _side: Dict[int, 'torch.cuda.Stream'] = {}
 _depth = 0
+_deferred: list = []
 
 
 def side_stream(device: torch.device) -> 'torch.cuda.Stream':
@@ -102,6 +111,15 @@ def inputs_ready(device: torch.device, data=None, module=None) -> None:
             side_stream(device).wait_stream(torch.cuda.current_stream(device))
 
 
+def defer(fn: Callable[[], None], inputs=()) -> None:
+    """Inside a preparation section: run ``fn`` (launches only, no host round trip; reads ``inputs`` produced by the
+    section) on the MAIN stream once the section is done.  Outside a section, or with deferral off, ``fn`` runs at once."""
+    if ENABLED and DEFER_HEAVY and _depth > 0:
+        _deferred.append((fn, tuple(inputs)))
+    else:
+        fn()
+
+
 def run_prep(device: torch.device, fn: Callable[[], object]):
     """Run ``fn`` (which must depend on ``data`` and on results of earlier sections only) on the side stream and make
     the current stream wait for it; returns ``fn()``.  Nested sections run inline in the enclosing one."""
@@ -117,6 +135,11 @@ def run_prep(device: torch.device, fn: Callable[[], object]):
             done = side.record_event()
     finally:
         _depth -= 1
-    _record(out, main, set())
+    seen: set = set()
+    _record(out, main, seen)
     main.wait_event(done)
+    pending, _deferred[:] = list(_deferred), []
+    for thunk, inputs in pending:        # on the main stream, in the order the section asked for them
+        _record(inputs, main, seen)
+        thunk()
     return out
