@@ -307,7 +307,7 @@ def main() -> None:
                                                          'a different batch every step, scenario ids disjoint across ranks and steps'),
                        'global_batch': world * batch_size, 'parallelism': 'scenario-sharded x%d' % world,
                        'matmul': MATMUL_NOTE[mode]},
-            'step_ms': None if not step_ms else {'median': statistics.median(step_ms), 'min': min(step_ms), 'max': max(step_ms),
+            'step_ms': None if not step_ms else {'median': statistics.median(step_ms), 'min': min(step_ms), 'max': max(step_ms), 'all': [round(v, 2) for v in step_ms],
                                                  'note': 'per-step GPU time between events on the main stream (rank 0); ms_per_step is '
                                                          'wall / steps of the pipelined loop'},
             'roofline': {'bound': 'hbm', 'kernel': 'attn_modes_kernel + attn_fused_kernel (qcn_attn_modes_*, qcn_attn_fused_f32: every positional attention launch)', 'achieved': achieved,
