@@ -197,6 +197,16 @@ def main() -> None:
             total = world * batch_size * args.steps
             step_ms = [marks[s].elapsed_time(marks[s + 1]) for s in range(args.steps)]
         ops.prof_enable(False)
+    # the same records per step (the host and the preparation stream run ahead of the main stream, so the last steps of a
+    # short run have the GPU to themselves: the per-step fractions show both regimes)
+    frac_by_step = []
+    attn_log = [r for r in ops._PROF_LOG if r[0] == ops.PROF_ATTN_FUSED]
+    if not pooled and attn_log and len(attn_log) % args.steps == 0:
+        per = len(attn_log) // args.steps
+        for s_ in range(args.steps):
+            recs = attn_log[s_ * per:(s_ + 1) * per]
+            ms_ = sum(r[2].elapsed_time(r[3]) for r in recs)
+            frac_by_step.append(round(sum(r[1] for r in recs) / (ms_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 3) if ms_ > 0 else None)
     launches, attn_ms, attn_bytes = ops.prof_collect(ops.PROF_ATTN_FUSED)
     ops.prof_collect(-1)
     # the MFMA chain kernels of the same steps (same regime: preparation stream on, batches cycled), bracketed in a pass of
@@ -313,7 +323,7 @@ def main() -> None:
             'roofline': {'bound': 'hbm', 'kernel': 'attn_modes_kernel + attn_fused_kernel (qcn_attn_modes_*, qcn_attn_fused_f32: every positional attention launch)', 'achieved': achieved,
                          'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'achievable_peak': copy_peak, 'frac_of_achievable': achieved / copy_peak if copy_peak > 0 else None,
-                         'launches': launches, 'avg_launch_us': attn_ms * 1e3 / max(launches, 1),
+                         'launches': launches, 'avg_launch_us': attn_ms * 1e3 / max(launches, 1), 'frac_by_step': frac_by_step,
                          'alg_bytes_per_launch': attn_bytes / max(launches, 1),
                          'formula': '1552*E + 1024*n_dst (SURVEY 8(d), r-projection fused; 1296*E in the bf16 mode: 256-byte rhat rows) with E = the edges a launch '
                                     'processes: a mode-replicated relation is processed once per base edge for all K modes; traffic = HBM '

@@ -260,8 +260,11 @@ class Batch(HeteroData):
         return out
 
 
-def frame_batch(data: HeteroData, first_shift: int, n_frames: int, num_steps: int) -> Batch:
+def frame_batch(data: HeteroData, first_shift: int, n_frames: int, num_steps: int, fields=None) -> Batch:
     """The sliding frames of one batch as ONE larger batch: scenario (f, b) is scenario b seen ``f`` steps later.
+
+    ``fields``: {node type: names} — replicate only these tensors (and only these node types) and leave the ``batch``
+    vectors out (their ``repeat_interleave`` is a host round trip); default: everything, like ``Batch.from_data_list``.
 
     Agent time series are shifted so that ``module(frame_batch(data, s0, F, n), ..., time_shift=s0)`` computes for rows
     [f * A, (f + 1) * A) what ``module(data, ..., time_shift=s0 + f)`` computes (``num_steps`` = steps kept after the
@@ -276,25 +279,29 @@ def frame_batch(data: HeteroData, first_shift: int, n_frames: int, num_steps: in
     for name, value in agent.items():
         if not torch.is_tensor(value) or name in ('batch', 'ptr'):
             continue
+        if fields is not None and name not in fields.get('agent', ()):
+            continue
         if name in ('position', 'heading', 'velocity', 'valid_mask'):
             store[name] = torch.cat([value[:, f:f + num_steps] for f in range(F)], dim=0)
         else:
             store[name] = value.repeat(F, *([1] * (value.dim() - 1)))
     out['agent'] = store
-    for ntype in data.node_types:
+    node_types = [t for t in data.node_types if fields is None or t in fields]
+    for ntype in node_types:
         if ntype != 'agent':
             n = int(data[ntype]['num_nodes'])
             out[ntype] = {'num_nodes': n * F}
             for name, value in data[ntype].items():
-                if torch.is_tensor(value) and name not in ('batch', 'ptr'):
+                if torch.is_tensor(value) and name not in ('batch', 'ptr') and (fields is None or name in fields[ntype]):
                     out[ntype][name] = value.repeat(F, *([1] * (value.dim() - 1)))
-    for ntype in data.node_types:
+    for ntype in node_types:
         n = int(data[ntype]['num_nodes'])
         dev = data[ntype]['position'].device
         ptr = data[ntype].get('ptr')
         ptr = ptr.to(dev) if ptr is not None else torch.tensor([0, n], device=dev)
         offs = (torch.arange(F, device=dev).unsqueeze(1) * n + ptr[:-1].unsqueeze(0)).reshape(-1)
         out[ntype]['ptr'] = torch.cat([offs, ptr.new_tensor([n * F])])
-        counts = out[ntype]['ptr'][1:] - out[ntype]['ptr'][:-1]
-        out[ntype]['batch'] = torch.repeat_interleave(torch.arange(num_graphs * F, device=dev), counts)
+        if fields is None:
+            counts = out[ntype]['ptr'][1:] - out[ntype]['ptr'][:-1]
+            out[ntype]['batch'] = torch.repeat_interleave(torch.arange(num_graphs * F, device=dev), counts)
     return out

@@ -6,6 +6,7 @@ from the HIP radius kernel with the validity filters of reference :160,170 fused
 to a destination-sorted CSR once and reused by both layers.  The T-fold tiling of the polygon features
 (reference :184) is folded away: sources are gathered from the single [P, C] copy.
 """
+import collections
 from typing import Dict, Mapping, Optional
 
 import torch
@@ -301,8 +302,7 @@ class QCNetAgentEncoder(nn.Module):
             raise AssertionError('layer-0 features differ from the long run at the first step only')
         NA = A * n_abs
         i64 = dict(device=dev, dtype=torch.int64)
-        a_ids = torch.arange(A, **i64)
-        frames = torch.arange(1, F, **i64)                                            # frames with special steps
+        shape = self._stream_shape_plan(D, A, F, n_abs, int(needed_from), dev)
 
         # long-run rows in time-major order (row u * A + a) through all layers: the spatial relations are time-major
         # anyway and the temporal edge list is simply numbered the same way, so nothing is ever transposed
@@ -322,34 +322,21 @@ class QCNetAgentEncoder(nn.Module):
         for l in range(1, NL + 1):
             Dp, Dl = D[l - 1], D[l]
             n_prev, n_own = (F - 1) * len(Dp) * A, (F - 1) * len(Dl) * A
-            own_idx = None
+            sh = shape['layers'][l - 1]
             rowptr, col, eid = rp_can, col_can, eid_can
             if n_own:
-                # the destinations' own rows (residual / query input): previous-layer value at (f, d)
-                own = []
-                for d in Dl:
-                    if d in Dp:
-                        own.append(NA + (((frames - 1) * len(Dp) + Dp.index(d)) * A).unsqueeze(1) + a_ids.unsqueeze(0))
-                    else:
-                        own.append(((frames + d) * A).unsqueeze(1) + a_ids.unsqueeze(0))                # [F-1, A]
-                own_idx = torch.stack(own, dim=1).reshape(n_own)
-                # their temporal edges: absolute edges into step f + d whose source lies inside frame f
-                d_vec = torch.tensor(Dl, **i64)
-                u_dst = (frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1)                          # [J]
-                f_of = frames.unsqueeze(1).expand(-1, len(Dl)).reshape(-1)
+                # the special destinations' temporal edges: absolute edges into step f + d whose source lies inside frame f
+                u_dst, f_of = sh['u_dst'], sh['f_of']
                 hit = (t_dst.unsqueeze(0) == u_dst.unsqueeze(1)) & (t_src.unsqueeze(0) >= f_of.unsqueeze(1))
                 j_sel, e_sel = hit.nonzero(as_tuple=True)
                 ag, fj = t_agent[e_sel], f_of[j_sel]
                 dp = t_src[e_sel] - fj                                                                  # source offset
-                pos_in_prev = torch.full((T + 1,), -1, **i64)
-                if Dp:
-                    pos_in_prev[torch.tensor(Dp, **i64)] = torch.arange(len(Dp), **i64)
-                slot = pos_in_prev[dp.clamp(0, T)]
+                slot = sh['pos_in_prev'][dp.clamp(0, T)]
                 is_special = dp <= (l - 1) * S
                 src_special = NA + n_own + ((fj - 1) * max(len(Dp), 1) + slot.clamp_min(0)) * A + ag
                 # (j_sel, e_sel) ascend in (j, edge) order and the cached edges are row-major in (agent, source step), so
                 # the special destinations j * A + agent ascend with sources ascending inside a row: CSR order already
-                first = torch.searchsorted(j_sel * A + ag, torch.arange(n_own + 1, **i64)) + E_abs
+                first = torch.searchsorted(j_sel * A + ag, sh['own_rows']) + E_abs
                 rowptr = torch.cat([rp_can[:NA], first.to(torch.int32),
                                     torch.full((n_prev,), E_abs + int(e_sel.numel()), dtype=torch.int32, device=dev)])
                 col = torch.cat([col_can, torch.where(is_special, src_special, t_src[e_sel] * A + ag).to(torch.int32)])
@@ -359,25 +346,77 @@ class QCNetAgentEncoder(nn.Module):
 
             # spatial relations over [long run | special rows (f, d, a)]
             if n_own:
-                u_rows = ((frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1, 1) * A + a_ids.unsqueeze(0)).reshape(-1)
-                row_index = torch.cat([torch.arange(NA, **i64), u_rows])
-                blk = NA + torch.arange(n_own, **i64)
-                src_offset = torch.cat([torch.zeros(NA, **i64), blk - blk % A - (u_rows - u_rows % A)])
-                g_pl2a = cache['g_pl2a'].with_rows(row_index, None, P)
-                g_a2a = cache['g_a2a'].with_rows(row_index, src_offset, NA + n_own)
+                g_pl2a = cache['g_pl2a'].with_rows(sh['row_index'], None, P)
+                g_a2a = cache['g_a2a'].with_rows(sh['row_index'], sh['src_offset'], NA + n_own)
             else:
                 g_pl2a, g_a2a = cache['g_pl2a'], cache['g_a2a']
-            layers.append(dict(n_own=n_own, own_idx=own_idx, g_t=g_t, g_pl2a=g_pl2a, g_a2a=g_a2a))
+            layers.append(dict(n_own=n_own, own_idx=sh['own_idx'], g_t=g_t, g_pl2a=g_pl2a, g_a2a=g_a2a))
+        return dict(z0=z0, layers=layers, index=shape['index'])
 
+    _SHAPE_PLANS: 'collections.OrderedDict' = collections.OrderedDict()
+    _SHAPE_PLAN_LIMIT = 8
+
+    def _stream_shape_plan(self, D, A: int, F: int, n_abs: int, needed_from: int, dev) -> dict:
+        """The part of :meth:`_stream_plan_graphs` that depends on SHAPES only (number of agents / frames / steps and the
+        streaming plan ``D``): the gather of the special destinations' own rows, their (frame, offset) lists, the
+        per-destination CSR-row / source-offset indirections of the spatial relations and the final (frame, agent, step)
+        -> table-row index.  ~100 small launches of index arithmetic when built; kept per shape (a few MB each, the
+        last ``_SHAPE_PLAN_LIMIT`` shapes) — batches of the same size reuse them, and the tensors are read-only."""
+        T, S, NL = self.num_historical_steps, self.time_span, self.num_layers
+        key = (T, S, NL, A, F, n_abs, needed_from, str(dev))
+        plans = QCNetAgentEncoder._SHAPE_PLANS
+        hit = plans.get(key)
+        if hit is not None:
+            plans.move_to_end(key)
+            if hit['ready'] is not None:
+                torch.cuda.current_stream(dev).wait_event(hit['ready'])      # built on whichever stream was current then
+            return hit
+        NA = A * n_abs
+        i64 = dict(device=dev, dtype=torch.int64)
+        a_ids = torch.arange(A, **i64)
+        frames = torch.arange(1, F, **i64)                                            # frames with special steps
+        layers = []
+        for l in range(1, NL + 1):
+            Dp, Dl = D[l - 1], D[l]
+            n_own = (F - 1) * len(Dl) * A
+            sh = dict(own_idx=None)
+            if n_own:
+                # the destinations' own rows (residual / query input): previous-layer value at (f, d)
+                own = []
+                for d in Dl:
+                    if d in Dp:
+                        own.append(NA + (((frames - 1) * len(Dp) + Dp.index(d)) * A).unsqueeze(1) + a_ids.unsqueeze(0))
+                    else:
+                        own.append(((frames + d) * A).unsqueeze(1) + a_ids.unsqueeze(0))                # [F-1, A]
+                sh['own_idx'] = torch.stack(own, dim=1).reshape(n_own)
+                d_vec = torch.tensor(Dl, **i64)
+                sh['u_dst'] = (frames.unsqueeze(1) + d_vec.unsqueeze(0)).reshape(-1)                    # [J]
+                sh['f_of'] = frames.unsqueeze(1).expand(-1, len(Dl)).reshape(-1).contiguous()
+                pos_in_prev = torch.full((T + 1,), -1, **i64)
+                if Dp:
+                    pos_in_prev[torch.tensor(Dp, **i64)] = torch.arange(len(Dp), **i64)
+                sh['pos_in_prev'] = pos_in_prev
+                sh['own_rows'] = torch.arange(n_own + 1, **i64)
+                u_rows = (sh['u_dst'].reshape(-1, 1) * A + a_ids.unsqueeze(0)).reshape(-1)
+                sh['row_index'] = torch.cat([torch.arange(NA, **i64), u_rows]).to(torch.int32)
+                blk = NA + torch.arange(n_own, **i64)
+                sh['src_offset'] = torch.cat([torch.zeros(NA, **i64), blk - blk % A - (u_rows - u_rows % A)]).to(torch.int32)
+            layers.append(sh)
         # every needed (frame, agent, step) as a row of ONE table: the long run's rows (u, a) followed by the special rows
         # of the last layer — consecutive frames share all but one of their steps, so the table has
         # n_abs + (F - 1) |D| rows per agent (time-major) where the dense [F, A, T] tensor has F * T
-        tail = torch.arange(int(needed_from), T, **i64)
+        tail = torch.arange(needed_from, T, **i64)
         steps = torch.arange(F, **i64).unsqueeze(1) + tail.unsqueeze(0)                                   # [F, Mt]
         index = (steps.view(F, 1, -1) * A + a_ids.view(1, A, 1)).contiguous()                            # [F, A, Mt]
         for i, d in enumerate(D[NL]):
-            index[1:, :, d - int(needed_from)] = NA + ((frames - 1).view(-1, 1) * len(D[NL]) + i) * A + a_ids.view(1, A)
-        return dict(z0=z0, layers=layers, index=index)
+            index[1:, :, d - needed_from] = NA + ((frames - 1).view(-1, 1) * len(D[NL]) + i) * A + a_ids.view(1, A)
+        plan = dict(layers=layers, index=index, ready=None)
+        if dev.type == 'cuda':
+            plan['ready'] = torch.cuda.current_stream(dev).record_event()
+        plans[key] = plan
+        while len(plans) > QCNetAgentEncoder._SHAPE_PLAN_LIMIT:
+            plans.popitem(last=False)
+        return plan
 
     @torch.no_grad()
     def forward_frames_streaming(self, data, map_enc: Mapping[str, torch.Tensor], cache, needed_from: int) -> torch.Tensor:

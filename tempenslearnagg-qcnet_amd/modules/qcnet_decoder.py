@@ -99,6 +99,10 @@ class QCNetDecoder(nn.Module):
         self.to_pi = MLPLayer(input_dim=hidden_dim, hidden_dim=hidden_dim, output_dim=1)
         self.apply(weight_init)
 
+    # the tensors forward() reads of its ``data`` argument (data.frame_batch replicates only these for the ten-frame pass)
+    DATA_FIELDS = {'agent': ('position', 'heading', 'valid_mask', 'predict_mask'),
+                   'map_polygon': ('position', 'orientation')}
+
     def _gru_packs(self):
         """traj_emb parameters in the kernels' layouts (k-major transposes), cached per parameter version."""
         gru = self.traj_emb

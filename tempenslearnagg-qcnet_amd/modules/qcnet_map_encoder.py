@@ -92,9 +92,10 @@ class QCNetMapEncoder(nn.Module):
 
             ei_pt2pl = data['map_point', 'to', 'map_polygon']['edge_index']
             g_pt2pl = CSRGraph.from_edge_index(ei_pt2pl, n_pt, n_pl)
-            r_pt2pl = NormalizedEdgeFeatures(self.r_pt2pl_emb(
-                continuous_inputs=geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl, z_pt if dim3 else None),
-                categorical_embs=None, normalized_output=True))
+            # the embedding launches themselves go to the main stream (utils/prep.py::defer)
+            geo_pt2pl = geometry(pos_pt, pos_pl, orient_pt, orient_pl, ei_pt2pl, z_pt if dim3 else None)
+            r_pt2pl = NormalizedEdgeFeatures.deferred(lambda: self.r_pt2pl_emb(
+                continuous_inputs=geo_pt2pl, categorical_embs=None, normalized_output=True), (geo_pt2pl,))
 
             ptr_pl = node_ptr(data, 'map_polygon', pos_pl.device)
             ei_radius, _ = ops.radius_pairs(pos_pl, pos_pl, self.pl2pl_radius, ptr_pl, ptr_pl, 300 + 1, drop_self=True,
@@ -104,9 +105,10 @@ class QCNetMapEncoder(nn.Module):
                 edge_indices=[ei_radius, data['map_polygon', 'to', 'map_polygon']['edge_index']],
                 edge_attrs=[type_data.new_zeros(ei_radius.size(1), dtype=torch.uint8), type_data], reduce='max')
             g_pl2pl = CSRGraph.from_edge_index(ei_pl2pl, n_pl, n_pl)
-            r_pl2pl = NormalizedEdgeFeatures(self.r_pl2pl_emb(
-                continuous_inputs=geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl, z_pl if dim3 else None),
-                categorical_embs=[self.type_pl2pl_emb(type_pl2pl.long())], normalized_output=True))
+            geo_pl2pl = geometry(pos_pl, pos_pl, orient_pl, orient_pl, ei_pl2pl, z_pl if dim3 else None)
+            r_pl2pl = NormalizedEdgeFeatures.deferred(lambda: self.r_pl2pl_emb(
+                continuous_inputs=geo_pl2pl, categorical_embs=[self.type_pl2pl_emb(type_pl2pl.long())],
+                normalized_output=True), (geo_pl2pl, type_pl2pl))
 
             return x_pt, x_pl, g_pt2pl, r_pt2pl, g_pl2pl, r_pl2pl, ei_pl2pl, type_pl2pl
 

@@ -110,7 +110,8 @@ class TempEnsLearnAgg(nn.Module):
         cache = enc.agent_encoder.precompute(data, 1, n_f)
         # the frame batch replicates the map per frame; the decoder folds the polygon sources onto this one copy
         x_pl_frames = map_enc['x_pl']
-        frames = run_prep(dev, lambda: frame_batch(data, 1, n_f, T + 2))
+        # (only what QCNetDecoder reads of its `data`: no map points, no velocities, no batch vectors)
+        frames = run_prep(dev, lambda: frame_batch(data, 1, n_f, T + 2, fields=dec.DATA_FIELDS))
         if self.stream_encoder:
             Mt = min(dec.num_t2m_steps, T)
             table, index = enc.agent_encoder.stream_frames(data, map_enc, cache, T - Mt)           # [N, C], [F, A, Mt]
