@@ -160,6 +160,40 @@ def main_nms() -> None:
     print('wrote ref_nms.npz: %d agents, selections %s' % (n_agents, sel.shape))
 
 
+def main_geometry_edges() -> None:
+    """tests/golden/ref_geometry_edges.npz: the relative-geometry rows [|dp|, angle(heading_dst, dp), wrap(dheading)] of an
+    edge list, computed with the reference's own utils/geometry.py functions in the reference's call pattern
+    (modules/qcnet_agent_encoder.py:161-166, modules/qcnet_decoder.py:183-188) — the vectors the qcn_rel_geometry_f32
+    KERNEL is held to on the GPU (tests/test_gpu_graph.py), incl. zero displacements, equal headings and headings on the
+    wrap boundary."""
+    geo = _load('_ref_geometry', os.path.join(REF, 'utils', 'geometry.py'))
+    gen = torch.Generator().manual_seed(4321)
+    ns, nd, e = 400, 150, 6000
+    pos_s = torch.randn(ns, 2, generator=gen) * 40.0
+    pos_d = torch.randn(nd, 2, generator=gen) * 40.0
+    head_s = (torch.rand(ns, generator=gen) * 2 - 1) * math.pi
+    head_d = (torch.rand(nd, generator=gen) * 2 - 1) * math.pi
+    head_d[:4] = torch.tensor([0.0, math.pi, -math.pi, math.pi / 2])
+    ei = torch.stack([torch.randint(0, ns, (e,), generator=gen), torch.randint(0, nd, (e,), generator=gen)])
+    ei[0, :40] = torch.arange(40)
+    pos_s[ei[0, :40]] = pos_d[ei[1, :40]]                      # zero displacement
+    head_s[ei[0, 40:70]] = head_d[ei[1, 40:70]]                # zero heading difference
+    src, dst = ei[0], ei[1]
+    head_vec_d = torch.stack([head_d.cos(), head_d.sin()], dim=-1)
+    rel_pos = pos_s[src] - pos_d[dst]
+    rows = torch.stack([torch.norm(rel_pos[:, :2], p=2, dim=-1),
+                        geo.angle_between_2d_vectors(ctr_vector=head_vec_d[dst], nbr_vector=rel_pos[:, :2]),
+                        geo.wrap_angle(head_s[src] - head_d[dst])], dim=-1)
+    path = os.path.join(OUT, 'ref_geometry_edges.npz')
+    np.savez_compressed(path, pos_s=pos_s.numpy(), pos_d=pos_d.numpy(), head_s=head_s.numpy(), head_d=head_d.numpy(),
+                        edge_index=ei.numpy(), rows=rows.numpy())
+    print('wrote', path)
+
+
 if __name__ == '__main__':
-    main()
-    main_nms()
+    if len(sys.argv) > 1 and sys.argv[1] == 'geometry_edges':
+        main_geometry_edges()
+    else:
+        main()
+        main_nms()
+        main_geometry_edges()

@@ -163,6 +163,27 @@ def test_rel_geometry_kernel_matches_reference_helpers():
     assert empty.shape == (0, 3)
 
 
+@pytest.mark.gpu
+def test_rel_geometry_kernel_vs_reference_golden():
+    """qcn_rel_geometry_f32 against rows the REFERENCE's own utils/geometry.py produced (pinned: tests/golden/
+    ref_geometry_edges.npz, written by oracle/make_golden.py::main_geometry_edges in the reference's call pattern,
+    modules/qcnet_agent_encoder.py:161-166).  The kernel evaluates cos / sin / atan2 / sqrt on the GPU, the golden rows
+    come from the host's libm: agreement to 2e-6 absolute (angles, radians) and 1e-6 relative (distances); the
+    signed-zero rows (zero displacement: angle +0, not pi) and the wrap boundary must agree exactly."""
+    import os
+    import numpy as np
+    from tempenslearnagg_qcnet_amd import ops
+    E = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_geometry_edges.npz'))
+    pos_s, pos_d, head_s, head_d, ei, want = (torch.from_numpy(E[k]).to('cuda:0') for k in
+                                               ('pos_s', 'pos_d', 'head_s', 'head_d', 'edge_index', 'rows'))
+    got = ops.rel_geometry(pos_s.contiguous(), pos_d.contiguous(), head_s, head_d, ei, None)
+    assert got.shape == want.shape
+    assert torch.equal(got[:40, :2], want[:40, :2])                           # zero displacement: distance 0, angle +0
+    assert float(((got[:, 0] - want[:, 0]).abs() / want[:, 0].clamp_min(1e-3)).max()) < 1e-6
+    assert float((got[:, 1:] - want[:, 1:]).abs().max()) < 2e-6
+    assert torch.equal(got[40:70, 2] == 0, want[40:70, 2] == 0)               # equal headings: exactly zero where the reference's is
+
+
 @pytest.mark.parametrize('b,n,m,band,p_src,p_dst', [
     (7, 59, 59, (1, 10), 0.8, 0.8),          # temporal graph (modules/qcnet_agent_encoder.py:129-132)
     (50, 50, 6, None, 0.6, 0.9),             # time -> mode (bipartite, modules/qcnet_decoder.py:160-169)

@@ -47,6 +47,17 @@ def test_geometry_matches_reference_bitwise():
     assert float(w.min()) >= -math.pi - 1e-6 and float(w.max()) < math.pi + 1e-6
 
 
+def test_rel_geometry_rows_match_reference_bitwise():
+    """The oracle's and the product's torch forms of the relative-geometry rows against rows computed with the reference's
+    own helpers in the reference's call pattern (tests/golden/ref_geometry_edges.npz, oracle/make_golden.py::main_geometry_edges)."""
+    import os
+    from tempenslearnagg_qcnet_amd.modules._common import rel_geometry_torch
+    E = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'ref_geometry_edges.npz'))
+    pos_s, pos_d, head_s, head_d, ei, rows = (torch.from_numpy(E[k]) for k in ('pos_s', 'pos_d', 'head_s', 'head_d', 'edge_index', 'rows'))
+    assert torch.equal(oracle.rel_geometry(pos_s, pos_d, head_s, head_d, ei), rows)
+    assert torch.equal(rel_geometry_torch(pos_s, pos_d, head_s, head_d, ei), rows)
+
+
 def test_weight_init_rules_match_reference_statistics():
     lin = torch.nn.Linear(128, 384)
     weight_init(lin)
