@@ -144,3 +144,62 @@ def test_store_changes_drop_the_derived_cache_and_ready_mark():
     cat.copy_(new)
     rows1, _ = sharding.focal_index([0, 1], data)
     assert rows1.tolist() == pick
+
+
+def test_frame_batch_with_a_field_selection_equals_the_full_one_on_those_fields():
+    """data.frame_batch(fields=...) (what the ten-frame decoder pass uses: QCNetDecoder.DATA_FIELDS) replicates exactly the
+    selected tensors, with the same values, ptr vectors and node counts as the full form, and nothing else."""
+    from tempenslearnagg_qcnet_amd.data import frame_batch
+    from tempenslearnagg_qcnet_amd.modules import QCNetDecoder
+    data = make_batch([3, 4], **SCENE_TINY)
+    full = frame_batch(data, 1, 4, 52)
+    part = frame_batch(data, 1, 4, 52, fields=QCNetDecoder.DATA_FIELDS)
+    assert part.num_graphs == full.num_graphs == 8
+    assert set(part.node_types) == set(QCNetDecoder.DATA_FIELDS)
+    for ntype, names in QCNetDecoder.DATA_FIELDS.items():
+        assert part[ntype]['num_nodes'] == full[ntype]['num_nodes']
+        assert torch.equal(part[ntype]['ptr'], full[ntype]['ptr'])
+        assert 'batch' not in part[ntype] and 'batch' in full[ntype]
+        for name in names:
+            assert torch.equal(part[ntype][name], full[ntype][name]), (ntype, name)
+        assert set(k for k, v in part[ntype].items() if torch.is_tensor(v)) == set(names) | {'ptr'}
+
+
+def test_deferred_edge_features_outside_a_section_are_made_at_once():
+    """utils.prep.defer / NormalizedEdgeFeatures.deferred: outside a preparation section (and always on the CPU) the thunk
+    runs immediately; the object then is what the direct constructor gives."""
+    from tempenslearnagg_qcnet_amd.layers import NormalizedEdgeFeatures
+    from tempenslearnagg_qcnet_amd.utils import prep
+    ran = []
+    prep.defer(lambda: ran.append(1))
+    assert ran == [1] and prep._deferred == []
+    rows = torch.randn(5, 128)
+    lazy = NormalizedEdgeFeatures.deferred(lambda: rows, (rows,))
+    assert lazy.rhat is rows and lazy.num_rows == 5
+
+
+def test_streaming_shape_plans_are_kept_per_shape_and_bounded():
+    """QCNetAgentEncoder._stream_shape_plan: the shape-only index tensors of the streaming plan are built once per
+    (agents, frames, steps) shape, reused for the next batch of that shape and dropped least-recently-used first."""
+    from tempenslearnagg_qcnet_amd.modules import QCNetAgentEncoder
+    from tempenslearnagg_qcnet_amd.synthetic import config_scene
+    hp = config_scene('tiny')['hparams']
+    enc = QCNetAgentEncoder(dataset='argoverse_v2', input_dim=2, hidden_dim=128, num_historical_steps=50, time_span=10,
+                            pl2a_radius=50.0, a2a_radius=50.0, num_freq_bands=64, num_layers=2, num_heads=8, head_dim=16,
+                            dropout=0.1)
+    D = enc.streaming_plan(20)
+    QCNetAgentEncoder._SHAPE_PLANS.clear()
+    dev = torch.device('cpu')
+    p6 = enc._stream_shape_plan(D, 6, 10, 59, 20, dev)
+    assert enc._stream_shape_plan(D, 6, 10, 59, 20, dev) is p6                 # same shape: the same tensors
+    p7 = enc._stream_shape_plan(D, 7, 10, 59, 20, dev)
+    assert p7 is not p6 and p7['index'].shape == (10, 7, 30) and p6['index'].shape == (10, 6, 30)
+    # frame 0 reads the long run's rows (u * A + a); later frames read one special row per agent at offset 20
+    A, NA = 6, 6 * 59
+    assert int(p6['index'][0, 2, 0]) == 20 * A + 2 and int(p6['index'][3, 2, 5]) == (3 + 25) * A + 2
+    assert int(p6['index'][1, 0, 0]) >= NA and int(p6['index'][9, 5, 0]) == NA + 8 * A + 5
+    for a in range(8, 8 + QCNetAgentEncoder._SHAPE_PLAN_LIMIT + 2):
+        enc._stream_shape_plan(D, a, 10, 59, 20, dev)
+    assert len(QCNetAgentEncoder._SHAPE_PLANS) == QCNetAgentEncoder._SHAPE_PLAN_LIMIT
+    assert enc._stream_shape_plan(D, 6, 10, 59, 20, dev) is not p6             # evicted, rebuilt
+    QCNetAgentEncoder._SHAPE_PLANS.clear()
