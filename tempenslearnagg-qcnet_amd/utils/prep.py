@@ -1,7 +1,8 @@
 """Graph preparation on a second HIP stream.
 
-Everything a module derives from ``data`` alone — masks, radius searches, CSR builds, relative geometry, the positional
-Fourier embeddings — is a long chain of small launches with a few host round trips (``nonzero``, edge counts).  None of
+Everything a module derives from ``data`` alone — masks, radius searches, CSR builds, relative geometry (and, until the
+big ones were handed back to the main stream with ``defer``, the positional Fourier embeddings) — is a long chain of
+small launches with a few host round trips (``nonzero``, edge counts).  None of
 it depends on the learned node features, so ``run_prep`` executes such a section on a per-device side stream: its host
 round trips then wait for the side stream only, the host keeps enqueueing, and the small launches overlap the attention
 / MLP kernels of the main stream (those of the previous module, or of the previous ``predict`` call).  The main stream
@@ -122,7 +123,8 @@ def defer(fn: Callable[[], None], inputs=()) -> None:
 
 def run_prep(device: torch.device, fn: Callable[[], object]):
     """Run ``fn`` (which must depend on ``data`` and on results of earlier sections only) on the side stream and make
-    the current stream wait for it; returns ``fn()``.  Nested sections run inline in the enclosing one."""
+    the current stream wait for it; returns ``fn()``.  Nested sections run inline in the enclosing one.  Work the
+    section handed back with ``defer`` is enqueued on the current stream before this returns."""
     global _depth
     if not ENABLED or _depth > 0 or device.type != 'cuda':
         return fn()
@@ -133,6 +135,9 @@ def run_prep(device: torch.device, fn: Callable[[], object]):
         with torch.cuda.stream(side):
             out = fn()
             done = side.record_event()
+    except BaseException:
+        _deferred.clear()        # a section that failed leaves no work behind for the next one
+        raise
     finally:
         _depth -= 1
     seen: set = set()
