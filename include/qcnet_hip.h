@@ -173,6 +173,31 @@ int qcn_attn_modes_bf16(const float *q, const float *k, const float *v, const vo
                         const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
                         int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream);
 
+/* The same relation applied SEVERAL TIMES to the same sources by the same layer — the decoder's recurrent proposal steps
+ * (modules/qcnet_decoder.py:219-227 run t2m / pl2m attention layer i three times on unchanged x_t / x_pl and unchanged
+ * weights; only the mode queries change): the per-edge terms kk_e = k[j] + W_kr LN_r(r_e), vv_e = v[j] + W_vr LN_r(r_e) are
+ * the same in every application.
+ *   qcn_attn_modes_store_f32 / _bf16: qcn_attn_modes_f32 / _bf16, and additionally writes kk_e, vv_e of every edge to
+ *     kk_out, vv_out — [num_edges, 128] fp32 each, row = CSR slot (position in col) — num_edges < 2^23.
+ *   qcn_attn_modes_cached_f32: the propagate from those two tables (q [n_dst,128], rowptr [n_rows+1], bv as above; no
+ *     k / v / rhat / col / eid / weights): bit-identical to what qcn_attn_modes_* returns for the same q, at 1 KiB read
+ *     per edge and without the projection MFMAs.  The caller keeps kk / vv alive and unchanged between the calls and
+ *     guarantees that sources, graph and layer weights are those of the storing call.  The reference recomputes the
+ *     projections in every step (layers/attention_layer.py:94-101 inside each propagate). */
+int qcn_attn_modes_store_f32(const float *q, const float *k, const float *v, const void *rhat_split,
+                             const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                             const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                             int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
+                             float *kk_out, float *vv_out, void *stream);
+int qcn_attn_modes_store_bf16(const float *q, const float *k, const float *v, const void *rhat_bf16,
+                              const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                              const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                              int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
+                              float *kk_out, float *vv_out, void *stream);
+int qcn_attn_modes_cached_f32(const float *q, const float *kk, const float *vv, const int32_t *rowptr, const float *bv,
+                              int64_t n_dst, int64_t n_rows, int64_t num_edges, int rep, int layout, float *out,
+                              void *stream);
+
 /* Arithmetic of the MFMA chain kernels below (qcn_fourier_*_f32, qcn_ln_linear_f32, qcn_attn_post_f32, qcn_mlp_heads_f32,
  * qcn_gru_f32): their `matmul_mode` argument.  The library keeps no mode of its own (no global mutable state: every call
  * names its arithmetic, calls are re-entrant); weight packs are mode specific — pass the pack made for the same mode.

@@ -62,6 +62,9 @@ struct ModesArgs {
     float *out;
     int n_rows, rep, layout, col_shift;
     unsigned long long *stamps;    // QCN_MODES_STAMPS builds only
+    // per-edge projections kk_e / vv_e in CSR-slot order, [slots, 128] fp32 each: written by the STORE instantiations of
+    // attn_modes_kernel, read by attn_kv_kernel (qcn_attn_modes_store_* / qcn_attn_modes_cached_f32)
+    float *kk, *vv;
 };
 
 // one 16-edge tile of one CSR row: edges [j0, j0 + 16) clipped to `end`
@@ -313,7 +316,7 @@ constexpr int kDepth = QCN_MODES_DEPTH;   // 3 .. 5
 constexpr int kBufs = kDepth + 1;
 constexpr int kIdxAhead = 2;
 
-template <bool HAS_EID, bool BF16>
+template <bool HAS_EID, bool BF16, bool STORE = false>
 __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 {
     static_assert(kBufs >= 4 && kBufs <= 6, "one __shared__ slot per ring position below");
@@ -459,6 +462,24 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         }
     };
 
+    // STORE: the tile's projections go to global memory in CSR-slot order (edge j0 + e -> row j0 + e): kk as one 16-B store
+    // per lane (row e = i, floats 16 w + 4 g ..), vv as four 4-B stores (rows 4 g + r, float 16 w + i) — kStoreOps
+    // vector-memory stores per tile, which the counted waits of the pipeline allow for
+    constexpr int kStoreOps = STORE ? 5 : 0;
+    auto store_kv = [&](const Tile &t, const f32x4 &kk_t, const f32x4 &vv_t) {
+        if constexpr (STORE) {
+            // Every lane stores, always (the waits count instructions): positions past the row's end hold the projection
+            // of the row's last edge — their DMAs were clamped to it — and are written to ITS slot, the same bits again.
+            if (t.row >= 0) {         // (uniform; without a next tile the iteration returns before its wait)
+                const int last_slot = t.end - 1;
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(a.kk) + ((uint32_t)min(t.j0 + i, last_slot) * 512u + 64u * wave + 16u * g)) = kk_t;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(a.vv) + ((uint32_t)min(t.j0 + 4 * g + r, last_slot) * 512u + 64u * wave + 4u * i)) = vv_t[r];
+            }
+        }
+    };
+
     // prologue: DMAs + q of tiles 0 .. kDepth - 1, indices of tiles kDepth .. kDepth + kIdxAhead - 1, projection of tile 0
     {
         auto fill = [&](auto ph) {
@@ -489,6 +510,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 #define STAMP(k)
 #endif
     project(&s_0, kk, vv, [](int) {});
+    store_kv(tl[0], kk, vv);
 
     // one iteration with the current tile in ring slot S; returns true after the last tile
     auto step = [&](auto ph) -> bool {
@@ -559,6 +581,7 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         o += o2;
         kk = kk_n;
         vv = vv_n;
+        store_kv(tl[1], kk, vv);
         STAMP(3)
 
         const bool last = tl[1].row != t0.row;                  // last tile of its row
@@ -570,8 +593,9 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         // the DMAs of tile n + 2 have landed (vmcnt) and this wave's LDS reads are done (lgkmcnt 0); a raw barrier:
         // __syncthreads() would add a release fence, i.e. vmcnt(0)
         // (the four output stores of a row's last tile are younger than this iteration's loads and count as well)
-        if (last && a.rep >= 4) __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps + 4));
-        else __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps));
+        // (STORE: this iteration's kStoreOps projection stores are younger than its loads as well)
+        if (last && a.rep >= 4) __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps + kStoreOps + 4));
+        else __builtin_amdgcn_s_waitcnt(wait_imm((kDepth - 2) * kOps + kStoreOps));
         STAMP(5)
         __builtin_amdgcn_s_barrier();
         STAMP(6)
@@ -594,6 +618,122 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         a.stamps[wave * 8 + 7] = n_it;
     }
 #endif
+}
+
+// The same relation with the per-edge projections ALREADY in memory (kk, vv in CSR-slot order, written by a STORE launch
+// of the kernel above for the same graph, layer and sources): the decoder's recurrent proposal steps apply one layer to
+// the same sources three times (modules/qcnet_decoder.py:219-227), so steps two and three only need
+//   logit[mode, e] = q[mode, head] . kk_e[head],   out[mode, head] = sum_e softmax_e(logit) vv_e[head]
+// — per tile and wave five loads (kk: 16 B per lane, vv: 4 x 4 B, q), the eight fp32 MFMAs and the softmax of the kernel
+// above, in the same order on the same bits (the result is bit-identical to recomputing the projections).  No LDS ring,
+// no weights, no barriers: the eight waves (heads) of a workgroup walk the same row chunk independently; loads run
+// kKvDepth tiles ahead in compile-time register slots (the compiler's own waitcnt bookkeeping suffices for plain loads).
+constexpr int kKvDepth = 3;
+constexpr int kKvBufs = kKvDepth + 1;
+
+__global__ __launch_bounds__(64 * kHeads) void attn_kv_kernel(ModesArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float s_t[kHeads][16 * kTStride];            // alpha transposition
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, g = lane >> 4;
+    const int nb = gridDim.x;
+    const int lb = qcn_xcd_remap(blockIdx.x, gridDim.x);
+    int row_begin, row_end;
+    row_chunk(a.rowptr, a.n_rows, lb, nb, lane, &row_begin, &row_end);
+    const float bias = a.bv[16 * wave + i];
+    float *const s_tw = s_t[wave];
+    const NodeAddr na = make_node_addr(a, wave, lane);
+
+    for (int row = row_begin; row < row_end; ++row) {          // rows without edges produce zeros
+        if (rowptr_at(a, row + 1) > rowptr_at(a, row)) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (4 * g + r < a.rep) *reinterpret_cast<float *>(reinterpret_cast<char *>(a.out) + ((uint32_t)row * na.row_mul + na.o_lane[r])) = 0.f;
+    }
+
+    Tile tl[kKvBufs];                                            // tiles n .. n + kKvDepth
+    tl[0] = first_tile(a, row_begin, row_end);
+    if (tl[0].row < 0) return;
+#pragma unroll
+    for (int j = 1; j < kKvBufs; ++j) tl[j] = next_tile(a, tl[j - 1], row_end);
+
+    f32x4 kkr[kKvBufs], qr[kKvBufs];
+    float vvr[kKvBufs][4];
+    auto request = [&](auto ph, const Tile &t_in) {
+        constexpr int S = decltype(ph)::value;
+        const Tile t = t_in.row >= 0 ? t_in : tl[0];             // past the last tile: a harmless duplicate
+        const int last_slot = t.end - 1;
+        kkr[S] = ld_off<f32x4>(a.kk, (uint32_t)min(t.j0 + i, last_slot) * 512u + 64u * wave + 16u * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            vvr[S][r] = ld_off<float>(a.vv, (uint32_t)min(t.j0 + 4 * g + r, last_slot) * 512u + 64u * wave + 4u * i);
+        qr[S] = load_q(a, na, t.row);
+    };
+    request(std::integral_constant<int, 0>{}, tl[0]);
+    request(std::integral_constant<int, 1>{}, tl[1]);
+    request(std::integral_constant<int, 2>{}, tl[2]);
+
+    f32x4 qa = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+    float m[4], l[4];
+    auto step = [&](auto ph) -> bool {
+        constexpr int S = decltype(ph)::value;
+        constexpr int SB = (S + kKvDepth) % kKvBufs;
+        const Tile t0 = tl[0];
+        request(std::integral_constant<int, SB>{}, tl[kKvDepth]);
+        const Tile tn = next_tile(a, tl[kKvDepth], row_end);
+        if (t0.first) {
+            qa = qr[S] * (0.25f * kLog2e);
+            if (i >= a.rep) qa = f32x4{0.f, 0.f, 0.f, 0.f};
+            o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { m[r] = -INFINITY; l[r] = 0.f; }
+        }
+        const f32x4 kk = kkr[S];
+        f32x4 p = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[0], kk[0], p, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[1], kk[1], p2, 0, 0, 0);
+        p = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[2], kk[2], p, 0, 0, 0);
+        p2 = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[3], kk[3], p2, 0, 0, 0);
+        const bool valid = t0.j0 + i < t0.end;
+        p += p2;
+        float pv[4], mx[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pv[r] = valid ? p[r] : -INFINITY; mx[r] = pv[r]; }
+        row16_max4(mx);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float mn = fmaxf(m[r], mx[r]);
+            const float corr = __builtin_amdgcn_exp2f(m[r] - mn);
+            m[r] = mn;
+            p[r] = __builtin_amdgcn_exp2f(pv[r] - mn);
+            l[r] = fmaf(l[r], corr, p[r]);
+            o[r] *= corr;
+            s_tw[(4 * g + r) * kTStride + i] = p[r];
+        }
+        wave_lds_fence();
+        const f32x4 pa = *reinterpret_cast<const f32x4 *>(s_tw + i * kTStride + 4 * g);   // alpha[mode = i][e = 4 g + r]
+        wave_lds_fence();
+        f32x4 o2 = {0.f, 0.f, 0.f, 0.f};
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[0], vvr[S][0], o, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[1], vvr[S][1], o2, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[2], vvr[S][2], o, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[3], vvr[S][3], o2, 0, 0, 0);
+        o += o2;
+        if (tl[1].row != t0.row) store_row_out(a, na, t0.row, g, l, o, bias);     // last tile of its row
+        if (tl[1].row < 0) return true;
+#pragma unroll
+        for (int j = 0; j + 1 < kKvBufs; ++j) tl[j] = tl[j + 1];
+        tl[kKvBufs - 1] = tn;
+        return false;
+    };
+    while (true) {
+        if (step(std::integral_constant<int, 0>{})) break;
+        if (step(std::integral_constant<int, 1>{})) break;
+        if (step(std::integral_constant<int, 2>{})) break;
+        if (step(std::integral_constant<int, 3>{})) break;
+    }
 }
 
 // Lean variant: two ring slots, no projection-ahead, at most 128 registers — two workgroups per CU, so that one
@@ -776,8 +916,11 @@ extern "C" size_t qcn_attn_modes_pack_bytes(void) { return (size_t)kHeads * 2 * 
 static int launch_attn_modes(bool bf16, const float *q, const float *k, const float *v, const void *rhat_op,
                              const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                              const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
-                             int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream)
+                             int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream,
+                             bool store = false, float *kk_out = nullptr, float *vv_out = nullptr)
 {
+    if (store && num_edges > 0 && (!kk_out || !vv_out)) return QCN_ERR_INVALID_ARGUMENT;
+    if (store && num_edges >= ((int64_t)1 << 23)) return QCN_ERR_UNSUPPORTED;       // slots by 32-bit byte offsets
     if (n_dst < 0 || n_src < 0 || n_rows < 0 || num_edges < 0 || rep < 1 || rep > 6) return QCN_ERR_INVALID_ARGUMENT;
     if (layout != 1 && layout != 2) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows * rep != n_dst) return QCN_ERR_INVALID_ARGUMENT;
@@ -792,7 +935,7 @@ static int launch_attn_modes(bool bf16, const float *q, const float *k, const fl
     const int64_t max_rows = (int64_t)1 << 23;
     if (n_dst >= max_rows || n_src >= max_rows || n_feat_rows >= max_rows) return QCN_ERR_UNSUPPORTED;
     ModesArgs args{q, k, v, rhat_op, rowptr, col, eid, reinterpret_cast<const half8 *>(wpack), bv, out, (int)n_rows, rep,
-                   layout, (int)col_shift, nullptr};
+                   layout, (int)col_shift, nullptr, kk_out, vv_out};
 #ifdef QCN_MODES_STAMPS
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long));
@@ -807,8 +950,16 @@ static int launch_attn_modes(bool bf16, const float *q, const float *k, const fl
     hipStream_t s = qcn_stream(stream);
     // QCN_MODES_LEAN=1: the two-workgroups-per-CU variant (same results; measured equal on cfg3, kept for A/B runs)
     const char *lean_env = getenv("QCN_MODES_LEAN");
-    const bool lean = !bf16 && lean_env && atoi(lean_env) != 0;
-    if (lean) {
+    const bool lean = !store && !bf16 && lean_env && atoi(lean_env) != 0;
+    if (store) {
+        if (bf16) {
+            if (eid) hipLaunchKernelGGL((attn_modes_kernel<true, true, true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+            else     hipLaunchKernelGGL((attn_modes_kernel<false, true, true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+        } else {
+            if (eid) hipLaunchKernelGGL((attn_modes_kernel<true, false, true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+            else     hipLaunchKernelGGL((attn_modes_kernel<false, false, true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
+        }
+    } else if (lean) {
         if (eid) hipLaunchKernelGGL((attn_modes_lean_kernel<true>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
         else     hipLaunchKernelGGL((attn_modes_lean_kernel<false>), dim3((unsigned)grid), dim3(64 * kHeads), 0, s, args);
     } else if (bf16) {
@@ -841,6 +992,46 @@ extern "C" int qcn_attn_modes_f32(const float *q, const float *k, const float *v
 {
     return launch_attn_modes(false, q, k, v, rhat_split, rowptr, col, eid, wpack, bv, n_dst, n_src, n_rows, num_edges,
                              n_feat_rows, rep, layout, col_shift, out, stream);
+}
+
+extern "C" int qcn_attn_modes_store_f32(const float *q, const float *k, const float *v, const void *rhat_split,
+                                        const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                                        const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                                        int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
+                                        float *kk_out, float *vv_out, void *stream)
+{
+    return launch_attn_modes(false, q, k, v, rhat_split, rowptr, col, eid, wpack, bv, n_dst, n_src, n_rows, num_edges,
+                             n_feat_rows, rep, layout, col_shift, out, stream, true, kk_out, vv_out);
+}
+
+extern "C" int qcn_attn_modes_store_bf16(const float *q, const float *k, const float *v, const void *rhat_bf16,
+                                         const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
+                                         const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
+                                         int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
+                                         float *kk_out, float *vv_out, void *stream)
+{
+    return launch_attn_modes(true, q, k, v, rhat_bf16, rowptr, col, eid, wpack, bv, n_dst, n_src, n_rows, num_edges,
+                             n_feat_rows, rep, layout, col_shift, out, stream, true, kk_out, vv_out);
+}
+
+extern "C" int qcn_attn_modes_cached_f32(const float *q, const float *kk, const float *vv, const int32_t *rowptr,
+                                         const float *bv, int64_t n_dst, int64_t n_rows, int64_t num_edges, int rep,
+                                         int layout, float *out, void *stream)
+{
+    if (n_dst < 0 || n_rows < 0 || num_edges < 0 || rep < 1 || rep > 6) return QCN_ERR_INVALID_ARGUMENT;
+    if (layout != 1 && layout != 2) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_rows * rep != n_dst) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_dst == 0) return QCN_OK;
+    if (!q || !out || !rowptr || !bv) return QCN_ERR_INVALID_ARGUMENT;
+    if (num_edges > 0 && (!kk || !vv)) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_dst >= ((int64_t)1 << 23) || num_edges >= ((int64_t)1 << 23)) return QCN_ERR_UNSUPPORTED;   // 32-bit byte offsets
+    ModesArgs args{q, nullptr, nullptr, nullptr, rowptr, nullptr, nullptr, nullptr, bv, out, (int)n_rows, rep, layout, 0,
+                   nullptr, const_cast<float *>(kk), const_cast<float *>(vv)};
+    // two workgroups per CU: the kernel holds no LDS ring and few registers, and its waves only wait for loads
+    const int64_t grid = n_rows < 512 ? n_rows : 512;
+    hipLaunchKernelGGL(attn_kv_kernel, dim3((unsigned)grid), dim3(64 * kHeads), 0, qcn_stream(stream), args);
+    QCN_CHECK_LAUNCH();
+    return QCN_OK;
 }
 
 extern "C" size_t qcn_attn_modes_bf16_pack_bytes(void) { return (size_t)kHeads * 2 * 4 * 64 * 16; }

@@ -21,6 +21,11 @@ from ..utils.weight_init import weight_init
 USE_ATTN_MODES = os.environ.get('QCN_ATTN_MODES', '1') != '0'
 
 
+# keep the per-edge projections of a mode-replicated relation across repeated applications of a layer to the same sources
+# (qcn_attn_modes_store_* / qcn_attn_modes_cached_f32; QCN_EDGE_KV_CACHE=0: recompute them every time)
+CACHE_EDGE_PROJECTIONS = os.environ.get('QCN_EDGE_KV_CACHE', '1') != '0'
+
+
 class NormalizedEdgeFeatures:
     """Positional embeddings of a relation after the layer-independent half of ``attn_prenorm_r``:
     ``rhat = (r - mean) / sqrt(var + eps)`` per edge, [E_base, 128].  Every AttentionLayer that consumes the
@@ -240,8 +245,22 @@ class AttentionLayer(nn.Module):
             if self.uses_attn_modes(graph, n_dst, n_src, r.num_rows):
                 # mode-replicated relation: per-edge projections once per (row, edge) on the matrix cores — bf16 operands
                 # in the bf16 mode (BASELINE.json configs[3]), split f16 (fp32-equivalent) otherwise
-                agg = ops.attn_modes(q, k, v, r.bf16 if mode == ops.MATMUL_BF16 else r.split, graph.rowptr, graph.col,
-                                     graph.eid, packs['pos_modes'], bv, graph.rep, graph.layout, graph.col_shift)
+                r_op = r.bf16 if mode == ops.MATMUL_BF16 else r.split
+                if source_cache is not None and CACHE_EDGE_PROJECTIONS:
+                    # the caller applies this layer to the same sources again (source_cache contract): the per-edge
+                    # projections k[j] + W_kr LN_r(r_e), v[j] + W_vr LN_r(r_e) are the same every time — the first call
+                    # stores them in CSR-slot order, the later ones read them back instead of recomputing
+                    tag = (graph.rowptr.data_ptr(), graph.col.data_ptr(), graph.num_base_edges, mode)
+                    kept = source_cache.get(('edge_kv', self))
+                    if kept is not None and kept[0] == tag:
+                        agg = ops.attn_modes_cached(q, kept[1], kept[2], graph.rowptr, bv, graph.rep, graph.layout)
+                    else:
+                        agg, kk_e, vv_e = ops.attn_modes_store(q, k, v, r_op, graph.rowptr, graph.col, graph.eid,
+                                                               packs['pos_modes'], bv, graph.rep, graph.layout, graph.col_shift)
+                        source_cache[('edge_kv', self)] = (tag, kk_e, vv_e)
+                else:
+                    agg = ops.attn_modes(q, k, v, r_op, graph.rowptr, graph.col, graph.eid, packs['pos_modes'], bv,
+                                         graph.rep, graph.layout, graph.col_shift)
             else:
                 agg = ops.attn_fused(q, k, v, r.dense, graph.rowptr, graph.col, graph.eid, wk, wv, bv, graph.rep,
                                      graph.layout,

@@ -964,6 +964,87 @@ def _attn_modes(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, rep, layout, col_
     return out
 
 
+def attn_modes_store(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat_op: torch.Tensor, rowptr: torch.Tensor,
+                     col: torch.Tensor, eid: Optional[torch.Tensor], wpack: torch.Tensor, bv: torch.Tensor,
+                     rep: int, layout: int, col_shift: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """qcn_attn_modes_store_f32 / _bf16: ``attn_modes`` that also returns the per-edge projections
+    ``(out, kk [E, 128], vv [E, 128])`` in CSR-slot order for later ``attn_modes_cached`` calls on the same sources."""
+    return _op('attn_modes_store')(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, int(rep), int(layout), int(col_shift))
+
+
+def _attn_modes_store_fake(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, rep, layout, col_shift):
+    return torch.empty_like(q), q.new_empty((col.numel(), C)), q.new_empty((col.numel(), C))
+
+
+@_register('attn_modes_store', '(Tensor q, Tensor k, Tensor v, Tensor rhat_op, Tensor rowptr, Tensor col, Tensor? eid, '
+           'Tensor wpack, Tensor bv, int rep, int layout, int col_shift) -> (Tensor, Tensor, Tensor)', _attn_modes_store_fake)
+def _attn_modes_store(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, rep, layout, col_shift):
+    dev = q.device
+    lib = _lib.lib()
+    n_dst, n_src, num_edges = q.size(0), k.size(0), col.numel()
+    n_rows = rowptr.numel() - 1
+    bf16 = rhat_op.dtype == torch.bfloat16
+    _require(q, 'q', torch.float32, dev, (n_dst, C))
+    _require(k, 'k', torch.float32, dev, (n_src, C))
+    _require(v, 'v', torch.float32, dev, (n_src, C))
+    n_feat = None if eid is not None else num_edges
+    if bf16:
+        _require(rhat_op, 'rhat_bf16', torch.bfloat16, dev, (n_feat, C))
+        _require(wpack, 'wpack', torch.uint8, dev, (lib.qcn_attn_modes_bf16_pack_bytes(),))
+    else:
+        _require(rhat_op, 'rhat_split', torch.float16, dev, (n_feat, 2 * C))
+        _require(wpack, 'wpack', torch.uint8, dev, (lib.qcn_attn_modes_pack_bytes(),))
+    _require(rowptr, 'rowptr', torch.int32, dev, (n_rows + 1,))
+    _require(col, 'col', torch.int32, dev, (num_edges,))
+    if eid is not None:
+        _require(eid, 'eid', torch.int32, dev, (num_edges,))
+    _require(bv, 'bv', torch.float32, dev, (C,))
+    if n_rows * rep != n_dst or layout not in (LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR):
+        raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d) or plain layout' % (n_rows, rep, n_dst))
+    out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
+    kk = torch.empty(num_edges, C, dtype=torch.float32, device=dev)
+    vv = torch.empty(num_edges, C, dtype=torch.float32, device=dev)
+    fn, name = ((lib.qcn_attn_modes_store_bf16, 'qcn_attn_modes_store_bf16') if bf16
+                else (lib.qcn_attn_modes_store_f32, 'qcn_attn_modes_store_f32'))
+    # algorithmic bytes: the fused form's reads + the two projection rows written per edge
+    tok = _prof_begin(PROF_ATTN_FUSED, ((1296.0 if bf16 else 1552.0) + 1024.0) * num_edges + 1024.0 * n_dst, dev)
+    _lib.check(fn(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat_op), _ptr(rowptr), _ptr(col), _ptr(eid), _ptr(wpack), _ptr(bv), n_dst,
+                  n_src, n_rows, num_edges, rhat_op.size(0), int(rep), int(layout), int(col_shift), _ptr(out), _ptr(kk),
+                  _ptr(vv), _stream(dev)), name)
+    _prof_end(tok, dev)
+    return out, kk, vv
+
+
+def attn_modes_cached(q: torch.Tensor, kk: torch.Tensor, vv: torch.Tensor, rowptr: torch.Tensor, bv: torch.Tensor,
+                      rep: int, layout: int) -> torch.Tensor:
+    """qcn_attn_modes_cached_f32: the propagate of a mode-replicated relation from the stored per-edge projections of an
+    ``attn_modes_store`` call on the same sources, graph and layer (bit-identical to ``attn_modes`` for the same q)."""
+    return _op('attn_modes_cached')(q, kk, vv, rowptr, bv, int(rep), int(layout))
+
+
+@_register('attn_modes_cached', '(Tensor q, Tensor kk, Tensor vv, Tensor rowptr, Tensor bv, int rep, int layout) -> Tensor',
+           lambda q, kk, vv, rowptr, bv, rep, layout: torch.empty_like(q))
+def _attn_modes_cached(q, kk, vv, rowptr, bv, rep, layout):
+    dev = q.device
+    n_dst, num_edges = q.size(0), kk.size(0)
+    n_rows = rowptr.numel() - 1
+    _require(q, 'q', torch.float32, dev, (n_dst, C))
+    _require(kk, 'kk', torch.float32, dev, (num_edges, C))
+    _require(vv, 'vv', torch.float32, dev, (num_edges, C))
+    _require(rowptr, 'rowptr', torch.int32, dev, (n_rows + 1,))
+    _require(bv, 'bv', torch.float32, dev, (C,))
+    if n_rows * rep != n_dst or layout not in (LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR):
+        raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d) or plain layout' % (n_rows, rep, n_dst))
+    out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
+    # algorithmic bytes: the two projection rows per edge, q in and out per destination
+    tok = _prof_begin(PROF_ATTN_FUSED, 1024.0 * num_edges + 1024.0 * n_dst, dev)
+    _lib.check(_lib.lib().qcn_attn_modes_cached_f32(_ptr(q), _ptr(kk), _ptr(vv), _ptr(rowptr), _ptr(bv), n_dst, n_rows,
+                                                   num_edges, int(rep), int(layout), _ptr(out), _stream(dev)),
+               'qcn_attn_modes_cached_f32')
+    _prof_end(tok, dev)
+    return out
+
+
 def attn_modes_supported(n_dst: int, n_src: int, n_feat_rows: int) -> bool:
     """qcn_attn_modes_* address rows by 32-bit byte offsets: every row count must stay below 2^23 (beyond that
     AttentionLayer falls back to qcn_attn_fused_f32, which handles the same graph)."""

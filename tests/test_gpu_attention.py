@@ -270,6 +270,52 @@ def _attn_modes_case(layout, K, n_rows, n_src, E, heavy, empty_from):
     assert bool((got.cpu()[deg == 0] == 0).all())
 
 
+@pytest.mark.parametrize('layout,K,n_rows,n_src,E,heavy,empty_from,sorted_', [
+    (2, 6, 37, 50, 900, 100, 30, False),
+    (1, 6, 37, 50, 900, 100, 30, False),
+    (2, 6, 3000, 400, 90000, 300, None, False),   # more rows than workgroups, rows of 1 .. 300+ edges
+    (2, 3, 700, 90, 20000, None, None, True),     # no edge ids (COO order = CSR order), rep < 4
+    (2, 6, 5, 9, 0, None, None, False),
+])
+@pytest.mark.parametrize('bf16', [False, True])
+def test_attn_modes_store_and_cached_equal_recomputation(layout, K, n_rows, n_src, E, heavy, empty_from, sorted_, bf16):
+    """qcn_attn_modes_store_* returns what qcn_attn_modes_* returns and the per-edge projections kk_e = k[j] + W_kr LN_r(r_e),
+    vv_e = v[j] + W_vr LN_r(r_e) in CSR-slot order (checked against an fp64 form); qcn_attn_modes_cached_f32 with those tables
+    and ANOTHER q is bit-identical to qcn_attn_modes_* recomputing everything for that q (the decoder's recurrent proposal
+    steps: same layer, same sources, new mode queries)."""
+    base = _graph(n_src, n_rows, E, 43, heavy=heavy, empty_from=empty_from)
+    q, k, v, r = _feat(n_rows * K, 1, 1.5), _feat(n_src, 2, 1.5), _feat(n_src, 3), _feat(E, 4, 2.0)
+    q2 = _feat(n_rows * K, 21, 1.5)
+    w_kr, w_vr, b_vr, gamma, beta = _pos_weights(12)
+    g = CSRGraph.from_edge_index(base.to(DEV), n_src, n_rows)
+    if sorted_:      # edge ids dropped: feature rows in CSR order
+        r = r[g.eid.long().cpu()]
+        g = CSRGraph(None, n_src, n_rows, g.rowptr, g.col, None)
+    g = g.replicate(K, layout)
+    mode = ops.MATMUL_BF16 if bf16 else ops.MATMUL_SPLIT_F16
+    wpack = ops.pack_attn_modes((w_kr * gamma[None]).to(DEV), (w_vr * gamma[None]).to(DEV), mode=mode)
+    bv = (w_vr @ beta + b_vr).to(DEV).contiguous()
+    rhat = ops.row_normalize(r.to(DEV)) if E else torch.zeros(0, 128, device=DEV)
+    rs = rhat.bfloat16() if bf16 else ops.split_rows(rhat)
+    args = (k.to(DEV), v.to(DEV), rs, g.rowptr, g.col, g.eid, wpack, bv, K, layout)
+    plain = ops.attn_modes(q.to(DEV), *args)
+    out, kk, vv = ops.attn_modes_store(q.to(DEV), *args)
+    assert torch.equal(out, plain)
+    assert kk.shape == vv.shape == (E, 128)
+    if E:
+        rid = (g.eid if g.eid is not None else torch.arange(E, device=DEV)).long()
+        wk64, wv64 = (w_kr * gamma[None]).double().to(DEV), (w_vr * gamma[None]).double().to(DEV)
+        rh = rhat[rid].bfloat16().double() if bf16 else rhat[rid].double()
+        if bf16:
+            wk64, wv64 = wk64.float().bfloat16().double(), wv64.float().bfloat16().double()
+        want_kk = k.to(DEV).double()[g.col.long()] + rh @ wk64.t()
+        want_vv = v.to(DEV).double()[g.col.long()] + rh @ wv64.t()
+        assert rel_err(kk, want_kk) < 5e-6 and rel_err(vv, want_vv) < 5e-6
+    again = ops.attn_modes_cached(q2.to(DEV), kk, vv, g.rowptr, bv, K, layout)
+    assert torch.equal(again, ops.attn_modes(q2.to(DEV), *args))
+    assert torch.equal(ops.attn_modes_cached(q.to(DEV), kk, vv, g.rowptr, bv, K, layout), plain)
+
+
 @pytest.mark.parametrize('mode,h0_scale', [(0, 0.3), (1, 0.3), (1, 5.0)])
 def test_gru_kernel_matches_torch_gru(mode, h0_scale, restore_matmul_mode):
     """qcn_gru_f32 + input GEMM against torch.nn.GRU (CPU fp32), ragged sequence count (tail block), in both matmul

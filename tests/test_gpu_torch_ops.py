@@ -225,6 +225,13 @@ def test_op_attn_modes():
     for mode_id in range(K):                   # agent-major: destination node = row * K + mode
         want = c_attention(q[mode_id::K].contiguous(), k, v, kr, vr, ei)
         assert rel_err(got[mode_id::K], want) < 2e-5, mode_id
+    # the storing form returns the same result plus the per-edge projections; the cached form reproduces it from them
+    out, kk, vv = op('attn_modes_store')(dev(q), dev(k), dev(v), ops.split_rows(dev(rhat)), rowptr, col, eid,
+                                         ops.pack_attn_modes(dev(wk), dev(wv), mode=ops.MATMUL_SPLIT_F16), dev(bv), K,
+                                         ops.LAYOUT_AGENT_MAJOR, 0)
+    assert torch.equal(out, got) and kk.shape == vv.shape == (col.numel(), 128)
+    assert rel_err(kk, (k[col.long().cpu()] + kr[eid.long().cpu()])) < 5e-6
+    assert torch.equal(op('attn_modes_cached')(dev(q), kk, vv, rowptr, dev(bv), K, ops.LAYOUT_AGENT_MAJOR), got)
 
 
 def test_op_mask_pairs_and_coalesce_max():
