@@ -21,7 +21,7 @@ cal_w = by_kernel(write, 'row_normalize')[-3:]
 kf = cal_bytes / (sum(cal_f) / len(cal_f) * 1024.0)
 kw = cal_bytes / (sum(cal_w) / len(cal_w) * 1024.0)
 def attn(rows):
-    return [float(r['Counter_Value']) for r in rows if 'attn_fused_kernel' in r['Kernel_Name'] or 'attn_modes' in r['Kernel_Name']]
+    return [float(r['Counter_Value']) for r in rows if 'attn_fused_kernel' in r['Kernel_Name'] or 'attn_modes' in r['Kernel_Name'] or 'attn_kv_kernel' in r['Kernel_Name']]
 
 
 af, aw = attn(fetch), attn(write)

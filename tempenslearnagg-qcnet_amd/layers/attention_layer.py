@@ -246,7 +246,10 @@ class AttentionLayer(nn.Module):
                 # mode-replicated relation: per-edge projections once per (row, edge) on the matrix cores — bf16 operands
                 # in the bf16 mode (BASELINE.json configs[3]), split f16 (fp32-equivalent) otherwise
                 r_op = r.bf16 if mode == ops.MATMUL_BF16 else r.split
-                if source_cache is not None and CACHE_EDGE_PROJECTIONS:
+                # (not in the bf16 mode: there a projection is one MFMA on a 256-byte row and recomputing it is cheaper than
+                # reading 1 KiB of tables per edge — cfg4: 92.6 scenarios/s recomputing, 89.9 from tables)
+                if (source_cache is not None and CACHE_EDGE_PROJECTIONS and mode != ops.MATMUL_BF16
+                        and graph.num_base_edges < (1 << 23)):
                     # the caller applies this layer to the same sources again (source_cache contract): the per-edge
                     # projections k[j] + W_kr LN_r(r_e), v[j] + W_vr LN_r(r_e) are the same every time — the first call
                     # stores them in CSR-slot order, the later ones read them back instead of recomputing
