@@ -253,7 +253,7 @@ class AttentionLayer(nn.Module):
                     # the caller applies this layer to the same sources again (source_cache contract): the per-edge
                     # projections k[j] + W_kr LN_r(r_e), v[j] + W_vr LN_r(r_e) are the same every time — the first call
                     # stores them in CSR-slot order, the later ones read them back instead of recomputing
-                    tag = (graph.rowptr.data_ptr(), graph.col.data_ptr(), graph.num_base_edges, mode)
+                    tag = (graph.rowptr.data_ptr(), graph.col.data_ptr(), graph.num_base_edges, r_op.data_ptr(), k.data_ptr(), mode)
                     kept = source_cache.get(('edge_kv', self))
                     if kept is not None and kept[0] == tag:
                         agg = ops.attn_modes_cached(q, kept[1], kept[2], graph.rowptr, bv, graph.rep, graph.layout)
