@@ -144,14 +144,24 @@ def test_cfg4_one_dense_scenario_one_frame_vs_oracle(mode, restore_matmul_mode):
         assert torch.equal(got_enc[k].cpu(), want_enc[k]), k
     for k in EDGE_KEYS_DEC:
         assert torch.equal(got_pred[k].cpu(), want_pred[k]), k
+    fp32_pred = None
+    if mode == ops.MATMUL_BF16:                                   # the mode's own cost at this size: bf16 oracle vs fp32 oracle
+        with torch.no_grad():
+            fp32_pred, _ = oracle.qcnet_forward(sd, batch, 10, cfg['hparams'], p='base_model.')
     for k in OUT_KEYS + ('m',):
         if mode == ops.MATMUL_BF16:
-            err = rel_err(got_pred[k], want_pred[k])
-            print('cfg4 bf16 %s: max-norm rel err vs bf16 oracle %.2e' % (k, err))
-            # 5e-2 at this size (tests/test_gpu_bf16.py uses BF16_TOL_MODEL = 3e-2 on its small scenes): with 200 x 1000
-            # neighbourhoods the distance to the bf16 oracle moves by +-20 % whenever the fp32 summation order of a LayerNorm
-            # changes (measured across two kernel generations: m 2.5e-2 -> 3.1e-2, pi 2.6e-2 -> 2.4e-2) — bf16 roundings flip.
-            assert err < 5e-2, k
+            err, far, ofar = rel_err(got_pred[k], want_pred[k]), rel_err(got_pred[k], fp32_pred[k]), rel_err(want_pred[k], fp32_pred[k])
+            print('cfg4 bf16 %s: HIP vs bf16 oracle %.2e | HIP vs fp32 oracle %.2e | bf16 oracle vs fp32 oracle %.2e' % (k, err, far, ofar))
+            # Same three-way guard as tests/test_gpu_bf16.py:173-177 (the bar alone would pass a path that
+            # ignores the mode): the HIP result must be CLOSER to the bf16-operand oracle than the fp32 oracle is, and no
+            # further from fp32 than the mode itself.  The absolute bar is 5e-2 here against BF16_TOL_MODEL = 3e-2 on the
+            # small scenes: at 200 x 1000 a mode query's softmax runs over up to 1000 polygon edges whose logits each carry
+            # 2^-9 operand roundings, and HIP and oracle round activations that already differ by fp32 summation order, so a
+            # value on a bf16 rounding boundary lands on different sides and the difference compounds over 28 layers —
+            # measured across kernel generations m 2.5e-2 .. 3.1e-2, pi 2.4e-2 .. 2.6e-2, i.e. 0.3-0.4 of the mode's own
+            # distance to fp32 (printed above), which is what the guard holds it to.
+            assert err < 5e-2 and err < ofar, k
+            assert far < 3 * max(ofar, 1e-3) + err, k
         else:
             worst = assert_close(got_pred[k], want_pred[k], k)
             print('cfg4 %s: worst element at %.2f of the bar' % (k, worst))
