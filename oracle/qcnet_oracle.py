@@ -596,7 +596,12 @@ def temp_ens_learn_agg_forward(sd, data, hp, num_shifts: int = 10):
         temporal_m.append(pred['m'])
     temporal_m = torch.stack(temporal_m, dim=1)
     pred = decoder(sd, 'temporal_aggregate_layer.', data, scene_enc, num_shifts, hp, temporal_m=temporal_m)
-    pred['traj_refine'] = torch.cat([pred['loc_refine_pos'], pred['scale_refine_pos']], dim=-1)[..., :50, :]
+    od = hp['output_dim']
+    for stage in ('propose', 'refine'):                                                  # :204-220
+        cols = [pred['loc_%s_pos' % stage][..., :od], pred['scale_%s_pos' % stage][..., :od]]
+        if hp.get('output_head', False):
+            cols = [cols[0], pred['loc_%s_head' % stage], cols[1], pred['conc_%s_head' % stage]]
+        pred['traj_' + stage] = torch.cat(cols, dim=-1)[..., :50, :]
     pred['pi_softmax'] = F.softmax(pred['pi'], dim=-1)
     return pred
 

@@ -390,10 +390,10 @@ extern "C" int qcn_attn_fused_f32(const float *q, const float *k, const float *v
     // one workgroup per CU (136-144 KiB of LDS); every workgroup gets a contiguous chunk of work items.  Mode-replicated
     // graphs carry 3 (or 2) modes of a row per wave.
     int R = rep % 3 == 0 ? 3 : (rep % 2 == 0 ? 2 : 1);
-    if (const char *env = getenv("QCN_ATTN_R")) { const int want = atoi(env); if ((want == 1 || want == 2 || want == 3 || want == 6) && rep % want == 0) R = want; }
+    if (const char *env = qcn_knob("QCN_ATTN_R")) { const int want = atoi(env); if ((want == 1 || want == 2 || want == 3 || want == 6) && rep % want == 0) R = want; }
     const int waves = R == 1 ? kWaves : (R <= 3 ? kWaves / 2 : kWaves / 4);
     int64_t grid = (n_dst / R + waves - 1) / waves;
-    if (grid > 256) grid = 256;
+    if (grid > qcn_num_cus()) grid = qcn_num_cus();
     hipStream_t s = qcn_stream(stream);
 #define QCN_LAUNCH(E, RR) hipLaunchKernelGGL((attn_fused_kernel<E, RR>), dim3((unsigned)grid), dim3(64 * (RR == 1 ? kWaves : (RR <= 3 ? kWaves / 2 : kWaves / 4))), 0, s, args)
     if (eid) { if (R == 6) QCN_LAUNCH(true, 6); else if (R == 3) QCN_LAUNCH(true, 3); else if (R == 2) QCN_LAUNCH(true, 2); else QCN_LAUNCH(true, 1); }

@@ -945,11 +945,12 @@ static int launch_attn_modes(bool bf16, const float *q, const float *k, const fl
     // one workgroup per CU (the LDS ring admits only one at a time anyway): with two contiguous row chunks per CU the second
     // prologue / pipeline fill costs more than the finer partition returns (isolated attention roofline 0.497 -> 0.523)
     int per_cu = 1;
-    if (const char *env = getenv("QCN_MODES_WG_PER_CU")) { const int want = atoi(env); if (want >= 1 && want <= 8) per_cu = want; }
-    int64_t grid = n_rows < 256 * per_cu ? n_rows : 256 * per_cu;
+    if (const char *env = qcn_knob("QCN_MODES_WG_PER_CU")) { const int want = atoi(env); if (want >= 1 && want <= 8) per_cu = want; }
+    const int64_t n_cus = qcn_num_cus();
+    int64_t grid = n_rows < n_cus * per_cu ? n_rows : n_cus * per_cu;
     hipStream_t s = qcn_stream(stream);
     // QCN_MODES_LEAN=1: the two-workgroups-per-CU variant (same results; measured equal on cfg3, kept for A/B runs)
-    const char *lean_env = getenv("QCN_MODES_LEAN");
+    const char *lean_env = qcn_knob("QCN_MODES_LEAN");
     const bool lean = !store && !bf16 && lean_env && atoi(lean_env) != 0;
     if (store) {
         if (bf16) {
@@ -1028,7 +1029,8 @@ extern "C" int qcn_attn_modes_cached_f32(const float *q, const float *kk, const 
     ModesArgs args{q, nullptr, nullptr, nullptr, rowptr, nullptr, nullptr, nullptr, bv, out, (int)n_rows, rep, layout, 0,
                    nullptr, const_cast<float *>(kk), const_cast<float *>(vv)};
     // two workgroups per CU: the kernel holds no LDS ring and few registers, and its waves only wait for loads
-    const int64_t grid = n_rows < 512 ? n_rows : 512;
+    const int64_t wgs = 2 * (int64_t)qcn_num_cus();
+    const int64_t grid = n_rows < wgs ? n_rows : wgs;
     hipLaunchKernelGGL(attn_kv_kernel, dim3((unsigned)grid), dim3(64 * kHeads), 0, qcn_stream(stream), args);
     QCN_CHECK_LAUNCH();
     return QCN_OK;

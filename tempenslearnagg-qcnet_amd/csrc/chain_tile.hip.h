@@ -93,7 +93,7 @@ __device__ __forceinline__ void skew_end(const Skew &s) { if (s.on && !s.grp_b) 
 
 __host__ inline int chain_skew_mode(int dflt)
 {
-    if (const char *env = getenv("QCN_CHAIN_SKEW")) { const int m = atoi(env); if (m >= 0 && m <= 2) return m; }
+    if (const char *env = qcn_knob("QCN_CHAIN_SKEW")) { const int m = atoi(env); if (m >= 0 && m <= 2) return m; }
     return dflt;
 }
 
@@ -737,9 +737,10 @@ __device__ __forceinline__ void layer_norm_centered(f32x16 (&v)[4], const float 
 // a 4- (or 2-) wave block relative to an 8-wave block's 2.0, measured per kernel (MI355X, split mode, microseconds per
 // round of blocks: attn_post 50 / 100 — its four-wave blocks keep their rows in registers —, Fourier in = 3 43 / 57,
 // ln_linear x4 33 / 50).
-__host__ inline int pick_waves(int64_t n_rows, double small_cost = 1.08, int n_cus = 256)
+__host__ inline int pick_waves(int64_t n_rows, double small_cost = 1.08, int n_cus = 0)
 {
-    if (const char *env = getenv("QCN_CHAIN_WAVES")) { const int w = atoi(env); if (w == 2 || w == 4 || w == 8) return w; }
+    if (n_cus <= 0) n_cus = qcn_num_cus();
+    if (const char *env = qcn_knob("QCN_CHAIN_WAVES")) { const int w = atoi(env); if (w == 2 || w == 4 || w == 8) return w; }
     int best = 8;
     double best_cost = 1e300;
     for (int w = 8; w >= 2; w >>= 1) {

@@ -26,3 +26,28 @@ __device__ __forceinline__ unsigned qcn_xcd_remap(unsigned bid, unsigned nblocks
 }
 
 static inline hipStream_t qcn_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// The shipped library reads NO environment variable and holds no tunable state: launch parameters are fixed or arguments.
+// The A/B knobs of the kernel experiments (QCN_MODES_WG_PER_CU, QCN_MODES_LEAN, QCN_ATTN_R, QCN_PAIR_MIN_ROWS,
+// QCN_CHAIN_SKEW, QCN_CHAIN_WAVES) exist only in diagnostic builds (-DQCN_DEBUG_KNOBS, scripts/dbg/build_variant.sh).
+#ifdef QCN_DEBUG_KNOBS
+#include <stdlib.h>
+static inline const char *qcn_knob(const char *name) { return getenv(name); }
+#else
+static inline const char *qcn_knob(const char *) { return nullptr; }
+#endif
+
+// Compute units of the current device (grids of the persistent kernels are sized by it); read once per device.
+// Plain int cache: concurrent first calls write the same value.
+static inline int qcn_num_cus()
+{
+    static int cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cache[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cache[dev] = n;
+    }
+    return cache[dev];
+}

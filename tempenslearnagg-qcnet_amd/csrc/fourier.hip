@@ -225,7 +225,7 @@ extern "C" size_t qcn_fourier_pack_floats(int input_dim)
 static int64_t pair_min_rows()
 {
     static const int64_t v = [] {
-        const char *env = getenv("QCN_PAIR_MIN_ROWS");
+        const char *env = qcn_knob("QCN_PAIR_MIN_ROWS");
         return env ? (int64_t)atoll(env) : (int64_t)192 * kPairBlockRows;
     }();
     return v;

@@ -13,6 +13,7 @@ weight packers.  The arithmetic mode of the MFMA chain kernels is an ARGUMENT of
 """
 import ctypes
 import os
+import threading
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -818,8 +819,9 @@ def _attn_fused(q, k, v, rhat, rowptr, col, eid, wk, wv, bv, rep, layout, col_sh
 # the one every op of this module launches on).  Python-side state; libqcnet_hip.so itself keeps none.
 # ------------------------------------------------------------------------------------------------
 PROF_ATTN, PROF_ATTN_FUSED, PROF_FOURIER, PROF_GEMM = 0, 1, 2, 3
-_PROF_MASK = 0
+_PROF_MASK = 0                  # process-wide switch (bench.py); the log is shared by all host threads under _PROF_LOCK
 _PROF_LOG: list = []
+_PROF_LOCK = threading.Lock()
 
 
 def prof_enable(on, kinds=None) -> None:
@@ -842,23 +844,23 @@ def _prof_end(tok, dev) -> None:
         return
     stop = torch.cuda.Event(enable_timing=True)
     stop.record(torch.cuda.current_stream(dev))
-    _PROF_LOG.append(tok + (stop,))
+    with _PROF_LOCK:
+        _PROF_LOG.append(tok + (stop,))
 
 
 def prof_collect(kind: int = -1) -> Tuple[int, float, float]:
     """(launches, summed kernel ms, summed algorithmic units) of one kernel family (-1: all), then drops those records.
     Units: bytes for the attention kernels (2064 E + 1024 n_dst materialised, 1552 E + 1024 n_dst fused,
     1040 E + 1024 n_dst without positional terms), flop for the MFMA chain kernels."""
-    n, ms, units, rest = 0, 0.0, 0.0, []
-    for rec in _PROF_LOG:
-        if kind >= 0 and rec[0] != kind:
-            rest.append(rec)
-            continue
+    n, ms, units = 0, 0.0, 0.0
+    with _PROF_LOCK:
+        mine = [rec for rec in _PROF_LOG if kind < 0 or rec[0] == kind]
+        _PROF_LOG[:] = [rec for rec in _PROF_LOG if not (kind < 0 or rec[0] == kind)]
+    for rec in mine:
         rec[3].synchronize()
         n += 1
         ms += rec[2].elapsed_time(rec[3])
         units += rec[1]
-    _PROF_LOG[:] = rest
     return n, ms, units
 
 

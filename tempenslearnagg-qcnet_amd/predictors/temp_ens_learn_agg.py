@@ -7,6 +7,7 @@ Training (losses, optimiser, Lightning hooks) and checkpoint download are outsid
 built from explicit hyper-parameters instead of ``load_from_checkpoint``.
 """
 import os
+import threading
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -16,16 +17,18 @@ import torch.nn.functional as F
 from .. import ops
 from ..metrics import MotionMetrics
 from ..modules import TemporalAggregate
-from ..utils.prep import _record, inputs_ready, run_prep
+from ..utils.prep import inputs_ready, record_streams, run_prep
 
-_AGG_STREAMS: Dict[int, 'torch.cuda.Stream'] = {}
+_AGG_STREAMS: Dict[tuple, 'torch.cuda.Stream'] = {}     # per (host thread, device), like the preparation stream
+_AGG_LOCK = threading.Lock()
 
 
 def _aggregate_stream(device: torch.device) -> 'torch.cuda.Stream':
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _AGG_STREAMS:
-        _AGG_STREAMS[idx] = torch.cuda.Stream(device=device)
-    return _AGG_STREAMS[idx]
+    idx = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
+    with _AGG_LOCK:
+        if idx not in _AGG_STREAMS:
+            _AGG_STREAMS[idx] = torch.cuda.Stream(device=device)
+        return _AGG_STREAMS[idx]
 from .qcnet_sliding import QCNetSliding
 
 
@@ -82,7 +85,7 @@ class TempEnsLearnAgg(nn.Module):
         target = self.get_ground_truth(data, time_shift=10)
         eval_mask = data['agent']['category'] == 3
         pred['metric_records'] = self.metrics.update(pred['traj_refine'], pred['pi_softmax'], target, reg_mask, eval_mask,
-                                                     output_dim=self.output_dim, output_head=False)
+                                                     output_dim=self.output_dim, output_head=bool(self.output_head))
         return pred
 
     def forward(self, data, time_shift: int, map_enc=None, agent_cache=None
@@ -92,8 +95,18 @@ class TempEnsLearnAgg(nn.Module):
         return pred, scene_enc
 
     def _finish(self, pred: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        traj_refine = torch.cat([pred['loc_refine_pos'][..., :self.output_dim],
-                                 pred['scale_refine_pos'][..., :self.output_dim]], dim=-1)
+        """reference :204-220: [loc, (heading loc), scale, (heading concentration)] of the refined and proposed trajectories,
+        truncated to the first 50 future steps."""
+        od = self.output_dim
+        if self.output_head:
+            traj_propose = torch.cat([pred['loc_propose_pos'][..., :od], pred['loc_propose_head'],
+                                      pred['scale_propose_pos'][..., :od], pred['conc_propose_head']], dim=-1)
+            traj_refine = torch.cat([pred['loc_refine_pos'][..., :od], pred['loc_refine_head'],
+                                     pred['scale_refine_pos'][..., :od], pred['conc_refine_head']], dim=-1)
+        else:
+            traj_propose = torch.cat([pred['loc_propose_pos'][..., :od], pred['scale_propose_pos'][..., :od]], dim=-1)
+            traj_refine = torch.cat([pred['loc_refine_pos'][..., :od], pred['scale_refine_pos'][..., :od]], dim=-1)
+        pred['traj_propose'] = traj_propose[..., :50, :]
         pred['traj_refine'] = traj_refine[..., :50, :]
         pred['pi_softmax'] = F.softmax(pred['pi'], dim=-1)
         return pred
@@ -138,8 +151,8 @@ class TempEnsLearnAgg(nn.Module):
         if state is None:
             state = agg.propose(data, scene_last, n_f, return_edge_index=False)
         else:
-            _record(state, main, set())             # produced on the side stream, consumed (and freed) on the main stream
-            _record(scene_last, side, set())
+            record_streams(state, main)             # produced on the side stream, consumed (and freed) on the main stream
+            record_streams(scene_last, side)
             main.wait_event(done)
         return self._finish(agg.refine(state, temporal_m))
 

@@ -11,6 +11,7 @@ waits for the section's event before it consumes the results.
 The reference has no counterpart (it runs one eager stream); with ``QCN_PREP_STREAM=0`` the sections run inline.
 """
 import os
+import threading
 from typing import Callable, Dict
 
 import torch
@@ -25,14 +26,30 @@ ENABLED = os.environ.get('QCN_PREP_STREAM', '1') != '0'
 # region 146 -> 157 TF/s, attention launches unchanged.  QCN_PREP_DEFER=0 keeps the embeddings on the side stream.
 DEFER_HEAVY = os.environ.get('QCN_PREP_DEFER', '1') != '0'
 
-_side: Dict[int, 'torch.cuda.Stream'] = {}
-_depth = 0
-_deferred: list = []
+# Threading: a section's nesting depth and its deferred work belong to the host thread that runs it (one thread per GPU in
+# one process is a supported way to drive several devices): thread-local.  The side stream is per (thread, device) for
+# the same reason — two threads predicting on one device must not interleave their sections on one stream.
+_side: Dict[tuple, 'torch.cuda.Stream'] = {}
+_side_lock = threading.Lock()
+
+
+class _SectionState(threading.local):
+    def __init__(self) -> None:
+        self.depth = 0
+        self.deferred = []
+
+
+_state = _SectionState()
 
 
 def side_stream(device: torch.device) -> 'torch.cuda.Stream':
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _side:
+    idx = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
+    stream = _side.get(idx)
+    if stream is not None:
+        return stream
+    with _side_lock:
+        if idx in _side:
+            return _side[idx]
         # lowest priority the runtime offers: the preparation kernels fill the CUs the main stream leaves idle instead of
         # taking them from the attention / MLP kernels they overlap (QCN_PREP_PRIORITY overrides, 0 = same as main)
         prio = int(os.environ.get('QCN_PREP_PRIORITY', '0'))
@@ -40,7 +57,7 @@ def side_stream(device: torch.device) -> 'torch.cuda.Stream':
             _side[idx] = torch.cuda.Stream(device=device, priority=prio)
         except (RuntimeError, ValueError):
             _side[idx] = torch.cuda.Stream(device=device)
-    return _side[idx]
+        return _side[idx]
 
 
 def _record(obj, stream, seen) -> None:
@@ -67,6 +84,12 @@ def _record(obj, stream, seen) -> None:
         if hasattr(obj, '__dict__'):
             for v in vars(obj).values():
                 _record(v, stream, seen)
+
+
+def record_streams(obj, stream) -> None:
+    """Public form of the walk above: every GPU tensor reachable from ``obj`` (dicts, lists, objects) is marked as used on
+    ``stream`` for the caching allocator — for results produced on one stream and consumed on another."""
+    _record(obj, stream, set())
 
 
 def _parameter_versions(module) -> tuple:
@@ -115,8 +138,8 @@ def inputs_ready(device: torch.device, data=None, module=None) -> None:
 def defer(fn: Callable[[], None], inputs=()) -> None:
     """Inside a preparation section: run ``fn`` (launches only, no host round trip; reads ``inputs`` produced by the
     section) on the MAIN stream once the section is done.  Outside a section, or with deferral off, ``fn`` runs at once."""
-    if ENABLED and DEFER_HEAVY and _depth > 0:
-        _deferred.append((fn, tuple(inputs)))
+    if ENABLED and DEFER_HEAVY and _state.depth > 0:
+        _state.deferred.append((fn, tuple(inputs)))
     else:
         fn()
 
@@ -125,25 +148,24 @@ def run_prep(device: torch.device, fn: Callable[[], object]):
     """Run ``fn`` (which must depend on ``data`` and on results of earlier sections only) on the side stream and make
     the current stream wait for it; returns ``fn()``.  Nested sections run inline in the enclosing one.  Work the
     section handed back with ``defer`` is enqueued on the current stream before this returns."""
-    global _depth
-    if not ENABLED or _depth > 0 or device.type != 'cuda':
+    if not ENABLED or _state.depth > 0 or device.type != 'cuda':
         return fn()
     main = torch.cuda.current_stream(device)
     side = side_stream(device)
-    _depth += 1
+    _state.depth += 1
     try:
         with torch.cuda.stream(side):
             out = fn()
             done = side.record_event()
     except BaseException:
-        _deferred.clear()        # a section that failed leaves no work behind for the next one
+        _state.deferred.clear()  # a section that failed leaves no work behind for the next one
         raise
     finally:
-        _depth -= 1
+        _state.depth -= 1
     seen: set = set()
     _record(out, main, seen)
     main.wait_event(done)
-    pending, _deferred[:] = list(_deferred), []
+    pending, _state.deferred = _state.deferred, []
     for thunk, inputs in pending:        # on the main stream, in the order the section asked for them
         _record(inputs, main, seen)
         thunk()

@@ -172,7 +172,7 @@ def test_deferred_edge_features_outside_a_section_are_made_at_once():
     from tempenslearnagg_qcnet_amd.utils import prep
     ran = []
     prep.defer(lambda: ran.append(1))
-    assert ran == [1] and prep._deferred == []
+    assert ran == [1] and prep._state.deferred == []
     rows = torch.randn(5, 128)
     lazy = NormalizedEdgeFeatures.deferred(lambda: rows, (rows,))
     assert lazy.rhat is rows and lazy.num_rows == 5

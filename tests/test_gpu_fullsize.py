@@ -21,6 +21,7 @@ from tempenslearnagg_qcnet_amd.predictors import TempEnsLearnAgg
 from tempenslearnagg_qcnet_amd.synthetic import config_scene, make_batch
 
 pytestmark = pytest.mark.gpu
+BF16_TOL_MODEL = 3e-2   # as tests/test_gpu_bf16.py
 DEV = 'cuda:0'
 
 EDGE_KEYS_ENC = ('edge_index_pl2pl', 'edge_index_t', 'edge_index_pl2a', 'edge_index_a2a')
@@ -147,20 +148,31 @@ def test_cfg4_one_dense_scenario_one_frame_vs_oracle(mode, restore_matmul_mode):
     fp32_pred = None
     if mode == ops.MATMUL_BF16:                                   # the mode's own cost at this size: bf16 oracle vs fp32 oracle
         with torch.no_grad():
-            fp32_pred, _ = oracle.qcnet_forward(sd, batch, 10, cfg['hparams'], p='base_model.')
+            fp32_pred, fp32_enc = oracle.qcnet_forward(sd, batch, 10, cfg['hparams'], p='base_model.')
+        # Three-way guard (a max-norm bar alone would pass a path that ignores the mode), applied where
+        # it discriminates.  SHALLOW outputs (x_pl: 2 layers, x_a: 6 layers behind the inputs): the HIP result must be
+        # CLOSER to the bf16-operand oracle than the fp32 oracle is, as in tests/test_gpu_bf16.py:173-177.
+        for k, g, w, f in (('x_pl', got_enc['x_pl'][:, 0], want_enc['x_pl'][:, 0], fp32_enc['x_pl'][:, 0]),
+                           ('x_a', got_enc['x_a'], want_enc['x_a'], fp32_enc['x_a'])):
+            err, far, ofar = rel_err(g, w), rel_err(g, f), rel_err(w, f)
+            print('cfg4 bf16 %s: HIP vs bf16 oracle %.2e | HIP vs fp32 oracle %.2e | bf16 oracle vs fp32 oracle %.2e' % (k, err, far, ofar))
+            assert err < BF16_TOL_MODEL and err < ofar, k
+            assert far < 3 * max(ofar, 1e-3) + err, k
     for k in OUT_KEYS + ('m',):
         if mode == ops.MATMUL_BF16:
             err, far, ofar = rel_err(got_pred[k], want_pred[k]), rel_err(got_pred[k], fp32_pred[k]), rel_err(want_pred[k], fp32_pred[k])
             print('cfg4 bf16 %s: HIP vs bf16 oracle %.2e | HIP vs fp32 oracle %.2e | bf16 oracle vs fp32 oracle %.2e' % (k, err, far, ofar))
-            # Same three-way guard as tests/test_gpu_bf16.py:173-177 (the bar alone would pass a path that
-            # ignores the mode): the HIP result must be CLOSER to the bf16-operand oracle than the fp32 oracle is, and no
-            # further from fp32 than the mode itself.  The absolute bar is 5e-2 here against BF16_TOL_MODEL = 3e-2 on the
-            # small scenes: at 200 x 1000 a mode query's softmax runs over up to 1000 polygon edges whose logits each carry
-            # 2^-9 operand roundings, and HIP and oracle round activations that already differ by fp32 summation order, so a
-            # value on a bf16 rounding boundary lands on different sides and the difference compounds over 28 layers —
-            # measured across kernel generations m 2.5e-2 .. 3.1e-2, pi 2.4e-2 .. 2.6e-2, i.e. 0.3-0.4 of the mode's own
-            # distance to fp32 (printed above), which is what the guard holds it to.
-            assert err < 5e-2 and err < ofar, k
+            # DEEP outputs (28 more layers, softmax rows of up to 1000 polygon edges): measured on this scene, HIP, the bf16
+            # oracle and the fp32 oracle are MUTUALLY 1.1e-2 .. 1.5e-2 apart (loc 1.07e-2 / 1.11e-2 / 1.28e-2, scale_refine
+            # 1.53e-2 / 1.50e-2 / 1.40e-2) — HIP and oracle round activations that already differ by fp32 summation order, a
+            # value on a bf16 rounding boundary lands on different sides, and at this depth the two bf16 realisations have
+            # decorrelated: "closer to the bf16 oracle than fp32 is" no longer holds or fails for a reason (that is why the
+            # round-2 bar of 3e-2 broke at 3.07e-2 for `m` after an unrelated kernel change).  What the full-size run CAN tell
+            # at this depth: the result is AS FAR from the fp32 oracle as the mode itself (a path that ignored the mode
+            # would sit at far ~ 1e-6), not further (far <= 3 ofar + err), and within 5e-2 of the bf16 oracle.  The
+            # arithmetic contract itself is held at 1e-5 by the kernel-level tests (tests/test_gpu_bf16.py).
+            assert err < 5e-2, k
+            assert far > 0.3 * ofar, k
             assert far < 3 * max(ofar, 1e-3) + err, k
         else:
             worst = assert_close(got_pred[k], want_pred[k], k)

@@ -72,9 +72,13 @@ def test_hip_ten_frame_pass_vs_reference_class_bodies(case):
         for k in keys + ('final_m',):
             assert_close(got[k], S.want(case, k), k)
             assert rel_err(got[k], S.want(case, k)) < TOL, k
-        want_traj = torch.cat([S.want(case, 'loc_refine_pos'), S.want(case, 'scale_refine_pos')], dim=-1)[..., :50, :]
-        if not hp['output_head']:
-            assert_close(got['traj_refine'], want_traj, 'traj_refine')
+        for stage in ('propose', 'refine'):                  # predictors/temp_ens_learn_agg.py:204-220, both branches
+            cols = [S.want(case, 'loc_%s_pos' % stage), S.want(case, 'scale_%s_pos' % stage)]
+            if hp['output_head']:
+                cols = [cols[0], S.want(case, 'loc_%s_head' % stage), cols[1], S.want(case, 'conc_%s_head' % stage)]
+            want_traj = torch.cat(cols, dim=-1)[..., :50, :]
+            assert got['traj_' + stage].shape == want_traj.shape == (want_traj.size(0), 6, 50, 6 if hp['output_head'] else 4)
+            assert_close(got['traj_' + stage], want_traj, 'traj_' + stage)
         assert_close(got['pi_softmax'], torch.softmax(S.want(case, 'pi'), dim=-1), 'pi_softmax')
 
 

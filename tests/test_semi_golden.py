@@ -65,6 +65,11 @@ def test_oracle_ten_frame_loop_and_aggregate_vs_reference_class_bodies(case):
             assert torch.equal(pred[k], S.want(case, k)), k
         assert rel_err(pred[k], S.want(case, k)) < TOL, k
     assert torch.equal(pred['edge_index_pl2m_clone'], S.want(case, 'edge_index_pl2m_clone'))
+    width = 6 if hp['output_head'] else 4                      # predictors/temp_ens_learn_agg.py:204-220
+    assert pred['traj_refine'].shape == pred['traj_propose'].shape == (pred['pi'].size(0), 6, 50, width)
+    if hp['output_head']:
+        assert torch.equal(pred['traj_propose'][..., 2], S.want(case, 'loc_propose_head')[..., :50, 0])
+        assert torch.equal(pred['traj_propose'][..., 5], S.want(case, 'conc_propose_head')[..., :50, 0])
 
 
 @pytest.mark.parametrize('tag,bipartite,pos', [('bip_pos', True, True), ('self_pos', False, True),
