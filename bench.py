@@ -92,15 +92,20 @@ def cpu_baseline(hparams, scene, state_dict, n_many: int, bf16: bool, one_frame_
 
 
 def stream_copy_peak(device, n_bytes: int = 1 << 30, reps: int = 10) -> float:
-    """Achievable HBM bandwidth of this box: GB/s of a device-to-device copy (read + write) of a 1 GiB buffer."""
-    x = torch.empty(n_bytes, dtype=torch.uint8, device=device)
+    """Achievable HBM bandwidth of this box: GB/s (read + write) of the library's float4 streaming copy
+    (qcn_stream_copy, csrc/api.hip) on a 1 GiB buffer — the guide's microbenchmark, not a library memcpy on bytes
+    (``torch.copy_`` on uint8 read 20 % low and flattered ``frac_of_achievable``)."""
+    from tempenslearnagg_qcnet_amd import _lib
+    x = torch.zeros(n_bytes // 4, dtype=torch.float32, device=device)
     y = torch.empty_like(x)
-    y.copy_(x)
+    stream = torch.cuda.current_stream(device).cuda_stream
+    copy = lambda: _lib.check(_lib.lib().qcn_stream_copy(x.data_ptr(), y.data_ptr(), n_bytes, stream), 'qcn_stream_copy')
+    copy()
     torch.cuda.synchronize()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     start.record()
     for _ in range(reps):
-        y.copy_(x)
+        copy()
     stop.record()
     stop.synchronize()
     return 2.0 * n_bytes * reps / (start.elapsed_time(stop) * 1e-3) / 1e9

@@ -140,6 +140,11 @@ int qcn_attn_fused_f32(const float *q, const float *k, const float *v, const flo
                        int64_t num_edges, int rep, int layout, int64_t col_shift, const int32_t *row_index,
                        const int32_t *src_offset, float *out, void *stream);
 
+/* Measurement aid, no counterpart in the reference: dst[0 .. n_bytes) = src[0 .. n_bytes) as a float4 streaming copy
+ * (16-byte aligned pointers, n_bytes a multiple of 16).  bench.py times it on 1 GiB to report the box's ACHIEVABLE HBM
+ * bandwidth (read + write) next to the 8 TB/s peak of SURVEY.md 8(d). */
+int qcn_stream_copy(const void *src, void *dst, size_t n_bytes, void *stream);
+
 /* A3 for mode-replicated relations, on the matrix cores — same result as qcn_attn_fused_f32 with layout 1 or 2 and
  * rep <= 6 (the decoder's t2m / pl2m / a2m relations, modules/qcnet_decoder.py:190-226,259-263 with num_modes = 6):
  * per (CSR row, edge) the projected key / value  k[j] + to_k_r(LN_r(r_e)),  v[j] + to_v_r(LN_r(r_e))  are computed once
@@ -178,25 +183,36 @@ int qcn_attn_modes_bf16(const float *q, const float *k, const float *v, const vo
  * weights; only the mode queries change): the per-edge terms kk_e = k[j] + W_kr LN_r(r_e), vv_e = v[j] + W_vr LN_r(r_e) are
  * the same in every application.
  *   qcn_attn_modes_store_f32 / _bf16: qcn_attn_modes_f32 / _bf16, and additionally writes kk_e, vv_e of every edge to
- *     kk_out, vv_out — [num_edges, 128] fp32 each, row = CSR slot (position in col) — num_edges < 2^23.
- *   qcn_attn_modes_cached_f32: the propagate from those two tables (q [n_dst,128], rowptr [n_rows+1], bv as above; no
- *     k / v / rhat / col / eid / weights): bit-identical to what qcn_attn_modes_* returns for the same q, at 1 KiB read
- *     per edge and without the projection MFMAs.  The caller keeps kk / vv alive and unchanged between the calls and
+ *     the tables kk_out, vv_out: table_slots * 128 fp32 each (caller-allocated, contents need no initialisation),
+ *     table_slots >= qcn_attn_modes_table_slots(num_edges, n_rows) = (num_edges + 3 n_rows + 7) & ~3, a multiple of 4 and
+ *     < 2^23, else QCN_ERR_INVALID_ARGUMENT.  Layout: the edge at CSR position j of row r (r counted from the first row
+ *     of THIS rowptr) has slot
+ *       s = ((rowptr[r] + 3 r + 3) & ~3) + (j - rowptr[r])            — every row starts on a multiple of four slots —
+ *     and inside every group of four slots the heads are interleaved,
+ *       kk_out[s / 4][head][s % 4][c] = kk_e[16 head + c]     vv_out[s / 4][head][c][s % 4] = vv_e[16 head + c]   (c < 16),
+ *     so that a wave (= head) moves whole 256-byte pieces and the eight waves of a workgroup one contiguous 8 KiB per
+ *     16-edge tile and table; slots between rows are padding (ops.attn_modes_table_rows turns the tables back into
+ *     [num_edges, 128] rows).
+ *   qcn_attn_modes_cached_f32: the propagate from those two tables (q [n_dst,128], the SAME rowptr [n_rows+1] and
+ *     table_slots, bv as above; no k / v / rhat / col / eid / weights): bit-identical to what qcn_attn_modes_* returns for
+ *     the same q, at 1 KiB read per edge — two 16-byte loads per lane, 16-edge tile and head — and without the
+ *     projection MFMAs.  The caller keeps kk / vv alive and unchanged between the calls and
  *     guarantees that sources, graph and layer weights are those of the storing call.  The reference recomputes the
  *     projections in every step (layers/attention_layer.py:94-101 inside each propagate). */
+int64_t qcn_attn_modes_table_slots(int64_t num_edges, int64_t n_rows);
 int qcn_attn_modes_store_f32(const float *q, const float *k, const float *v, const void *rhat_split,
                              const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                              const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
                              int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
-                             float *kk_out, float *vv_out, void *stream);
+                             float *kk_out, float *vv_out, int64_t table_slots, void *stream);
 int qcn_attn_modes_store_bf16(const float *q, const float *k, const float *v, const void *rhat_bf16,
                               const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                               const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
                               int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
-                              float *kk_out, float *vv_out, void *stream);
+                              float *kk_out, float *vv_out, int64_t table_slots, void *stream);
 int qcn_attn_modes_cached_f32(const float *q, const float *kk, const float *vv, const int32_t *rowptr, const float *bv,
-                              int64_t n_dst, int64_t n_rows, int64_t num_edges, int rep, int layout, float *out,
-                              void *stream);
+                              int64_t n_dst, int64_t n_rows, int64_t num_edges, int64_t table_slots, int rep, int layout,
+                              float *out, void *stream);
 
 /* Arithmetic of the MFMA chain kernels below (qcn_fourier_*_f32, qcn_ln_linear_f32, qcn_attn_post_f32, qcn_mlp_heads_f32,
  * qcn_gru_f32): their `matmul_mode` argument.  The library keeps no mode of its own (no global mutable state: every call

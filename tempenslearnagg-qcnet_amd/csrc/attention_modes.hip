@@ -62,15 +62,61 @@ struct ModesArgs {
     float *out;
     int n_rows, rep, layout, col_shift;
     unsigned long long *stamps;    // QCN_MODES_STAMPS builds only
-    // per-edge projections kk_e / vv_e in CSR-slot order, [slots, 128] fp32 each: written by the STORE instantiations of
-    // attn_modes_kernel, read by attn_kv_kernel (qcn_attn_modes_store_* / qcn_attn_modes_cached_f32)
+    // per-edge projections kk_e / vv_e, written by the STORE instantiations of attn_modes_kernel, read by attn_kv_kernel
+    // (qcn_attn_modes_store_* / qcn_attn_modes_cached_f32).  HEAD-MAJOR tables of `table_slots` slots per head plane
+    // (include/qcnet_hip.h): edge j of CSR row r sits in slot s = ((rowptr[r] + 3 r + 3) & ~3) + (j - rowptr[r]) — every
+    // row starts on a multiple of four slots, in closed form, no scan —
+    //   kk[head][s][16]        : a wave's 16-edge tile is ONE contiguous 1 KiB (lane (e, g): 16 B at 64 s + 16 g)
+    //   vv[head][s / 4][16][4] : groups of four slots transposed, so that the B operand of the weighted sum (lane (g, d):
+    //                            channel d of edges 4 g .. 4 g + 3) is one 16-B load and the tile again 1 KiB contiguous.
+    // (that is the QCN_KV_PLANES form; the shipped form interleaves the heads per group of four slots, see kk_slot_off.
+    // Round 2 kept [slot][128] rows: 64-B fragments per (slot, head), six loads per tile and wave; 4.0 TB/s of tables.)
     float *kk, *vv;
+    long long table_slots;
 };
 
 // one 16-edge tile of one CSR row: edges [j0, j0 + 16) clipped to `end`
+// Table addressing (byte offsets inside a table; see ModesArgs::kk).  QCN_KV_PLANES=1 selects the head-plane form
+// kk[head][s][16] / vv[head][s / 4][16][4] (a wave's tile = 1 KiB contiguous, but 16 distant streams per workgroup: A/B
+// builds only); the default interleaves the heads inside every group of four slots,
+//   kk[s / 4][head][s % 4][16]     vv[s / 4][head][16][s % 4],
+// so that a workgroup's eight waves together read ONE contiguous 8 KiB per tile and table (row-buffer locality in HBM)
+// while every wave instruction still covers whole 256-B pieces (two full 128-B lines per piece).
+#ifndef QCN_KV_PLANES
+#define QCN_KV_PLANES 0
+#endif
+__device__ __forceinline__ uint32_t kk_slot_off(uint32_t slot, int head, int g)
+{
+#if QCN_KV_PLANES
+    (void)head;
+    return slot * 64u + 16u * g;
+#else
+    return (slot >> 2) * 2048u + (uint32_t)head * 256u + (slot & 3u) * 64u + 16u * g;
+#endif
+}
+__device__ __forceinline__ uint32_t vv_group_off(uint32_t group, int head, int d)
+{
+#if QCN_KV_PLANES
+    (void)head;
+    return group * 256u + 16u * d;
+#else
+    return group * 2048u + (uint32_t)head * 256u + 16u * d;
+#endif
+}
+__device__ __forceinline__ size_t kv_plane_base(int head, long long table_slots)
+{
+#if QCN_KV_PLANES
+    return (size_t)head * (size_t)table_slots * 64u;
+#else
+    (void)head; (void)table_slots;
+    return 0;
+#endif
+}
+
 struct Tile {
     int row, j0, end;              // row < 0: no tile
     bool first;                    // first tile of its row
+    int s0;                        // table slot of edge j0 (see ModesArgs::kk): a multiple of four
 };
 
 struct TileIdx {                   // indices of the edge whose rows this lane copies by DMA (clamped to valid edges)
@@ -256,16 +302,16 @@ __device__ __forceinline__ Tile first_tile(const ModesArgs &a, int row, int row_
 {
     while (row < row_end) {
         const int b = rowptr_at(a, row), e = rowptr_at(a, row + 1);
-        if (e > b) return Tile{row, b, e, true};
+        if (e > b) return Tile{row, b, e, true, (b + 3 * row + 3) & ~3};
         ++row;
     }
-    return Tile{-1, 0, 0, false};
+    return Tile{-1, 0, 0, false, 0};
 }
 
 __device__ __forceinline__ Tile next_tile(const ModesArgs &a, Tile t, int row_end)
 {
     if (t.row < 0) return t;
-    if (t.j0 + kTile < t.end) { t.j0 += kTile; t.first = false; return t; }
+    if (t.j0 + kTile < t.end) { t.j0 += kTile; t.s0 += kTile; t.first = false; return t; }
     return first_tile(a, t.row + 1, row_end);
 }
 
@@ -462,20 +508,23 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
         }
     };
 
-    // STORE: the tile's projections go to global memory in CSR-slot order (edge j0 + e -> row j0 + e): kk as one 16-B store
-    // per lane (row e = i, floats 16 w + 4 g ..), vv as four 4-B stores (rows 4 g + r, float 16 w + i) — kStoreOps
-    // vector-memory stores per tile, which the counted waits of the pipeline allow for
-    constexpr int kStoreOps = STORE ? 5 : 0;
+    // STORE: the tile's projections go to the head's planes of the tables (ModesArgs::kk): kk as one 16-B store per lane
+    // (slot of edge e = i, floats 4 g ..), vv as one 16-B store per lane (group of edges 4 g .. 4 g + 3, channel i) — each a
+    // contiguous 1 KiB per wave; kStoreOps vector-memory stores per tile, which the counted waits of the pipeline allow for
+    constexpr int kStoreOps = STORE ? 2 : 0;
+    char *const kk_plane = STORE ? reinterpret_cast<char *>(a.kk) + kv_plane_base(wave, a.table_slots) : nullptr;
+    char *const vv_plane = STORE ? reinterpret_cast<char *>(a.vv) + kv_plane_base(wave, a.table_slots) : nullptr;
     auto store_kv = [&](const Tile &t, const f32x4 &kk_t, const f32x4 &vv_t) {
         if constexpr (STORE) {
-            // Every lane stores, always (the waits count instructions): positions past the row's end hold the projection
-            // of the row's last edge — their DMAs were clamped to it — and are written to ITS slot, the same bits again.
+            // Both instructions are issued by every wave, always (the waits count instructions; group 0 of a tile is never
+            // empty).  kk: positions past the row's end hold the projection of the row's last edge — their DMAs were clamped
+            // to it — and are written to ITS slot, the same bits again.  vv: a group that begins past the row's end is
+            // masked off; the tail of the row's last group (its padding slots) receives the last edge's values.
             if (t.row >= 0) {         // (uniform; without a next tile the iteration returns before its wait)
-                const int last_slot = t.end - 1;
-                *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(a.kk) + ((uint32_t)min(t.j0 + i, last_slot) * 512u + 64u * wave + 16u * g)) = kk_t;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    *reinterpret_cast<float *>(reinterpret_cast<char *>(a.vv) + ((uint32_t)min(t.j0 + 4 * g + r, last_slot) * 512u + 64u * wave + 4u * i)) = vv_t[r];
+                const int last = t.end - 1 - t.j0;
+                *reinterpret_cast<f32x4 *>(kk_plane + kk_slot_off((uint32_t)(t.s0 + min(i, last)), wave, g)) = kk_t;
+                if (4 * g <= last)
+                    *reinterpret_cast<f32x4 *>(vv_plane + vv_group_off((uint32_t)((t.s0 >> 2) + g), wave, i)) = vv_t;
             }
         }
     };
@@ -630,8 +679,12 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
 // kKvDepth tiles ahead in compile-time register slots (the compiler's own waitcnt bookkeeping suffices for plain loads).
 constexpr int kKvDepth = 3;
 constexpr int kKvBufs = kKvDepth + 1;
+#ifndef QCN_KV_MIN_WAVES
+#define QCN_KV_MIN_WAVES 4       // waves per SIMD the register allocation must allow (2 per workgroup)
+#endif
+constexpr int kKvWgPerCu = QCN_KV_MIN_WAVES / 2;
 
-__global__ __launch_bounds__(64 * kHeads) void attn_kv_kernel(ModesArgs a)
+__global__ __launch_bounds__(64 * kHeads, QCN_KV_MIN_WAVES) void attn_kv_kernel(ModesArgs a)
 {
     __shared__ __attribute__((aligned(16))) float s_t[kHeads][16 * kTStride];            // alpha transposition
     const int tid = threadIdx.x;
@@ -659,16 +712,16 @@ __global__ __launch_bounds__(64 * kHeads) void attn_kv_kernel(ModesArgs a)
 #pragma unroll
     for (int j = 1; j < kKvBufs; ++j) tl[j] = next_tile(a, tl[j - 1], row_end);
 
-    f32x4 kkr[kKvBufs], qr[kKvBufs];
-    float vvr[kKvBufs][4];
+    f32x4 kkr[kKvBufs], vvr[kKvBufs], qr[kKvBufs];
+    const char *const kk_plane = reinterpret_cast<const char *>(a.kk) + kv_plane_base(wave, a.table_slots);
+    const char *const vv_plane = reinterpret_cast<const char *>(a.vv) + kv_plane_base(wave, a.table_slots);
     auto request = [&](auto ph, const Tile &t_in) {
         constexpr int S = decltype(ph)::value;
         const Tile t = t_in.row >= 0 ? t_in : tl[0];             // past the last tile: a harmless duplicate
-        const int last_slot = t.end - 1;
-        kkr[S] = ld_off<f32x4>(a.kk, (uint32_t)min(t.j0 + i, last_slot) * 512u + 64u * wave + 16u * g);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            vvr[S][r] = ld_off<float>(a.vv, (uint32_t)min(t.j0 + 4 * g + r, last_slot) * 512u + 64u * wave + 4u * i);
+        const int last = t.end - 1 - t.j0;
+        // positions / groups past the row's end re-read its last edge / last group (finite values; their weights are 0)
+        kkr[S] = ld_off<f32x4>(kk_plane, kk_slot_off((uint32_t)(t.s0 + min(i, last)), wave, g));
+        vvr[S] = ld_off<f32x4>(vv_plane, vv_group_off((uint32_t)((t.s0 >> 2) + min(g, last >> 2)), wave, i));
         qr[S] = load_q(a, na, t.row);
     };
     request(std::integral_constant<int, 0>{}, tl[0]);
@@ -911,16 +964,29 @@ extern "C" int qcn_split_rows_f16(const float *x, int64_t n_rows, int scale_log2
     return QCN_OK;
 }
 
+extern "C" int64_t qcn_attn_modes_table_slots(int64_t num_edges, int64_t n_rows)
+{
+    if (num_edges < 0 || n_rows < 0) return -1;
+    return (num_edges + 3 * n_rows + 7) & ~(int64_t)3;     // >= ((rowptr[r] + 3 r + 3) & ~3) + degree(r), rounded to a group
+}
+
+// slots are addressed by 32-bit byte offsets inside a head plane (64 B per slot)
+static bool table_slots_ok(int64_t table_slots, int64_t num_edges, int64_t n_rows)
+{
+    return table_slots >= qcn_attn_modes_table_slots(num_edges, n_rows) && (table_slots & 3) == 0 &&
+           table_slots < ((int64_t)1 << (QCN_KV_PLANES ? 26 : 23));
+}
+
 extern "C" size_t qcn_attn_modes_pack_bytes(void) { return (size_t)kHeads * 2 * 4 * 2 * 64 * 16 + 2 * sizeof(float); }
 
 static int launch_attn_modes(bool bf16, const float *q, const float *k, const float *v, const void *rhat_op,
                              const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                              const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
                              int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out, void *stream,
-                             bool store = false, float *kk_out = nullptr, float *vv_out = nullptr)
+                             bool store = false, float *kk_out = nullptr, float *vv_out = nullptr, int64_t table_slots = 0)
 {
     if (store && num_edges > 0 && (!kk_out || !vv_out)) return QCN_ERR_INVALID_ARGUMENT;
-    if (store && num_edges >= ((int64_t)1 << 23)) return QCN_ERR_UNSUPPORTED;       // slots by 32-bit byte offsets
+    if (store && !table_slots_ok(table_slots, num_edges, n_rows)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_dst < 0 || n_src < 0 || n_rows < 0 || num_edges < 0 || rep < 1 || rep > 6) return QCN_ERR_INVALID_ARGUMENT;
     if (layout != 1 && layout != 2) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows * rep != n_dst) return QCN_ERR_INVALID_ARGUMENT;
@@ -935,7 +1001,7 @@ static int launch_attn_modes(bool bf16, const float *q, const float *k, const fl
     const int64_t max_rows = (int64_t)1 << 23;
     if (n_dst >= max_rows || n_src >= max_rows || n_feat_rows >= max_rows) return QCN_ERR_UNSUPPORTED;
     ModesArgs args{q, k, v, rhat_op, rowptr, col, eid, reinterpret_cast<const half8 *>(wpack), bv, out, (int)n_rows, rep,
-                   layout, (int)col_shift, nullptr, kk_out, vv_out};
+                   layout, (int)col_shift, nullptr, kk_out, vv_out, (long long)table_slots};
 #ifdef QCN_MODES_STAMPS
     static unsigned long long *d_stamps = nullptr;
     if (!d_stamps) (void)hipMalloc(&d_stamps, 64 * sizeof(unsigned long long));
@@ -999,25 +1065,25 @@ extern "C" int qcn_attn_modes_store_f32(const float *q, const float *k, const fl
                                         const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                                         const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
                                         int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
-                                        float *kk_out, float *vv_out, void *stream)
+                                        float *kk_out, float *vv_out, int64_t table_slots, void *stream)
 {
     return launch_attn_modes(false, q, k, v, rhat_split, rowptr, col, eid, wpack, bv, n_dst, n_src, n_rows, num_edges,
-                             n_feat_rows, rep, layout, col_shift, out, stream, true, kk_out, vv_out);
+                             n_feat_rows, rep, layout, col_shift, out, stream, true, kk_out, vv_out, table_slots);
 }
 
 extern "C" int qcn_attn_modes_store_bf16(const float *q, const float *k, const float *v, const void *rhat_bf16,
                                          const int32_t *rowptr, const int32_t *col, const int32_t *eid, const void *wpack,
                                          const float *bv, int64_t n_dst, int64_t n_src, int64_t n_rows, int64_t num_edges,
                                          int64_t n_feat_rows, int rep, int layout, int64_t col_shift, float *out,
-                                         float *kk_out, float *vv_out, void *stream)
+                                         float *kk_out, float *vv_out, int64_t table_slots, void *stream)
 {
     return launch_attn_modes(true, q, k, v, rhat_bf16, rowptr, col, eid, wpack, bv, n_dst, n_src, n_rows, num_edges,
-                             n_feat_rows, rep, layout, col_shift, out, stream, true, kk_out, vv_out);
+                             n_feat_rows, rep, layout, col_shift, out, stream, true, kk_out, vv_out, table_slots);
 }
 
 extern "C" int qcn_attn_modes_cached_f32(const float *q, const float *kk, const float *vv, const int32_t *rowptr,
-                                         const float *bv, int64_t n_dst, int64_t n_rows, int64_t num_edges, int rep,
-                                         int layout, float *out, void *stream)
+                                         const float *bv, int64_t n_dst, int64_t n_rows, int64_t num_edges,
+                                         int64_t table_slots, int rep, int layout, float *out, void *stream)
 {
     if (n_dst < 0 || n_rows < 0 || num_edges < 0 || rep < 1 || rep > 6) return QCN_ERR_INVALID_ARGUMENT;
     if (layout != 1 && layout != 2) return QCN_ERR_INVALID_ARGUMENT;
@@ -1025,11 +1091,12 @@ extern "C" int qcn_attn_modes_cached_f32(const float *q, const float *kk, const 
     if (n_dst == 0) return QCN_OK;
     if (!q || !out || !rowptr || !bv) return QCN_ERR_INVALID_ARGUMENT;
     if (num_edges > 0 && (!kk || !vv)) return QCN_ERR_INVALID_ARGUMENT;
-    if (n_dst >= ((int64_t)1 << 23) || num_edges >= ((int64_t)1 << 23)) return QCN_ERR_UNSUPPORTED;   // 32-bit byte offsets
+    if (n_dst >= ((int64_t)1 << 23) || num_edges >= ((int64_t)1 << 31)) return QCN_ERR_UNSUPPORTED;   // 32-bit byte offsets
+    if (!table_slots_ok(table_slots, num_edges, n_rows)) return QCN_ERR_INVALID_ARGUMENT;
     ModesArgs args{q, nullptr, nullptr, nullptr, rowptr, nullptr, nullptr, nullptr, bv, out, (int)n_rows, rep, layout, 0,
-                   nullptr, const_cast<float *>(kk), const_cast<float *>(vv)};
+                   nullptr, const_cast<float *>(kk), const_cast<float *>(vv), (long long)table_slots};
     // two workgroups per CU: the kernel holds no LDS ring and few registers, and its waves only wait for loads
-    const int64_t wgs = 2 * (int64_t)qcn_num_cus();
+    const int64_t wgs = kKvWgPerCu * (int64_t)qcn_num_cus();
     const int64_t grid = n_rows < wgs ? n_rows : wgs;
     hipLaunchKernelGGL(attn_kv_kernel, dim3((unsigned)grid), dim3(64 * kHeads), 0, qcn_stream(stream), args);
     QCN_CHECK_LAUNCH();

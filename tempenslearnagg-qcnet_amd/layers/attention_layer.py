@@ -23,6 +23,23 @@ USE_ATTN_MODES = os.environ.get('QCN_ATTN_MODES', '1') != '0'
 
 # keep the per-edge projections of a mode-replicated relation across repeated applications of a layer to the same sources
 # (qcn_attn_modes_store_* / qcn_attn_modes_cached_f32; QCN_EDGE_KV_CACHE=0: recompute them every time)
+# Byte budget of ONE (layer, relation)'s pair of tables (1 KiB per base edge; six layer-relations are alive together during
+# a proposal phase, TemporalAggregate's overlapped half adds its own): beyond it — or when the allocator reports less than
+# twice that free — the layer recomputes the projections (no silent exhaustion of HBM at cfg4-like sizes).
+EDGE_TABLE_BUDGET_BYTES = int(os.environ.get('QCN_EDGE_KV_BUDGET_MB', '8192')) << 20
+
+
+def _tables_fit(graph, device) -> bool:
+    need = AttentionLayer.edge_table_bytes(graph)
+    if need > EDGE_TABLE_BUDGET_BYTES or ops.attn_modes_table_slots(graph.num_base_edges, graph.rowptr.numel() - 1) >= (1 << 23):
+        return False
+    if need > (256 << 20):          # only large tables are worth a driver query (cfg3: 2.1 GB for pl2m, 0.5 / 0.7 GB others)
+        free, _ = torch.cuda.mem_get_info(device)
+        reserved_free = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
+        return need * 2 < free + reserved_free
+    return True
+
+
 CACHE_EDGE_PROJECTIONS = os.environ.get('QCN_EDGE_KV_CACHE', '1') != '0'
 
 
@@ -229,11 +246,16 @@ class AttentionLayer(nn.Module):
         # pre: LayerNorm + q/k/v/s projections (one or two launches)
         if not single:
             ln_s, ln_d = self.attn_prenorm_x_src, self.attn_prenorm_x_dst
-            kv = source_cache.get(self) if source_cache is not None else None
-            if kv is None or kv[0].size(0) != n_src:
+            # (the cached projections are tagged by the source tensor's storage, version counter and shape and by the
+            # layer's parameter versions: a reused dict with other sources, or after a weight update, recomputes)
+            src_tag = (x_src.data_ptr(), x_src._version, tuple(x_src.shape), self._pack_key)
+            kept_kv = source_cache.get(self) if source_cache is not None else None
+            if kept_kv is None or kept_kv[0] != src_tag:
                 kv, _ = ops.ln_linear(x_src, ln_s.weight, ln_s.bias, *packs['pre_src'], mode=mode)
                 if source_cache is not None:
-                    source_cache[self] = kv
+                    source_cache[self] = (src_tag, kv, x_src)      # x_src kept alive: its address is part of the tag
+            else:
+                kv = kept_kv[1]
             k, v = kv
             (q, s), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'], mode=mode)
         else:
@@ -249,18 +271,24 @@ class AttentionLayer(nn.Module):
                 # (not in the bf16 mode: there a projection is one MFMA on a 256-byte row and recomputing it is cheaper than
                 # reading 1 KiB of tables per edge — cfg4: 92.6 scenarios/s recomputing, 89.9 from tables)
                 if (source_cache is not None and CACHE_EDGE_PROJECTIONS and mode != ops.MATMUL_BF16
-                        and graph.num_base_edges < (1 << 23)):
+                        and _tables_fit(graph, q.device)):
                     # the caller applies this layer to the same sources again (source_cache contract): the per-edge
                     # projections k[j] + W_kr LN_r(r_e), v[j] + W_vr LN_r(r_e) are the same every time — the first call
                     # stores them in CSR-slot order, the later ones read them back instead of recomputing
                     tag = (graph.rowptr.data_ptr(), graph.col.data_ptr(), graph.num_base_edges, r_op.data_ptr(), k.data_ptr(), mode)
                     kept = source_cache.get(('edge_kv', self))
                     if kept is not None and kept[0] == tag:
-                        agg = ops.attn_modes_cached(q, kept[1], kept[2], graph.rowptr, bv, graph.rep, graph.layout)
+                        agg = ops.attn_modes_cached(q, kept[1], kept[2], graph.rowptr, bv, graph.rep, graph.layout,
+                                                    graph.num_base_edges)
                     else:
-                        agg, kk_e, vv_e = ops.attn_modes_store(q, k, v, r_op, graph.rowptr, graph.col, graph.eid,
-                                                               packs['pos_modes'], bv, graph.rep, graph.layout, graph.col_shift)
-                        source_cache[('edge_kv', self)] = (tag, kk_e, vv_e)
+                        try:
+                            agg, kk_e, vv_e = ops.attn_modes_store(q, k, v, r_op, graph.rowptr, graph.col, graph.eid,
+                                                                   packs['pos_modes'], bv, graph.rep, graph.layout, graph.col_shift)
+                            source_cache[('edge_kv', self)] = (tag, kk_e, vv_e)
+                        except torch.cuda.OutOfMemoryError:      # no room for the tables: recompute
+                            source_cache.pop(('edge_kv', self), None)
+                            agg = ops.attn_modes(q, k, v, r_op, graph.rowptr, graph.col, graph.eid, packs['pos_modes'], bv,
+                                                 graph.rep, graph.layout, graph.col_shift)
                 else:
                     agg = ops.attn_modes(q, k, v, r_op, graph.rowptr, graph.col, graph.eid, packs['pos_modes'], bv,
                                          graph.rep, graph.layout, graph.col_shift)
@@ -275,6 +303,11 @@ class AttentionLayer(nn.Module):
         # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)
         # the gate's LN(x_dst) is recomputed inside the kernel (xn_dst = None): cheaper than a [N, 128] round trip
         return ops.attn_post(agg, None, s, x_res, packs['post'], mode=mode)
+
+    @staticmethod
+    def edge_table_bytes(graph: CSRGraph) -> int:
+        """Bytes of the two projection tables of one (layer, relation): 1 KiB per base edge plus the row padding."""
+        return 2 * 512 * ops.attn_modes_table_slots(graph.num_base_edges, graph.rowptr.numel() - 1)
 
     @staticmethod
     def uses_attn_modes(graph: CSRGraph, n_dst: int, n_src: int, n_feat_rows: int) -> bool:

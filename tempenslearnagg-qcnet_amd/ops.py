@@ -970,12 +970,14 @@ def attn_modes_store(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, rhat_op:
                      col: torch.Tensor, eid: Optional[torch.Tensor], wpack: torch.Tensor, bv: torch.Tensor,
                      rep: int, layout: int, col_shift: int = 0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """qcn_attn_modes_store_f32 / _bf16: ``attn_modes`` that also returns the per-edge projections
-    ``(out, kk [E, 128], vv [E, 128])`` in CSR-slot order for later ``attn_modes_cached`` calls on the same sources."""
+    ``(out, kk [slots / 4, 8, 4, 16], vv [slots / 4, 8, 16, 4])`` — (include/qcnet_hip.h; ``attn_modes_table_rows`` gives the
+    [E, 128] rows back) — for later ``attn_modes_cached`` calls on the same sources with the same ``rowptr``."""
     return _op('attn_modes_store')(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, int(rep), int(layout), int(col_shift))
 
 
 def _attn_modes_store_fake(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, rep, layout, col_shift):
-    return torch.empty_like(q), q.new_empty((col.numel(), C)), q.new_empty((col.numel(), C))
+    slots = attn_modes_table_slots(col.numel(), rowptr.numel() - 1)
+    return torch.empty_like(q), q.new_empty((slots // 4, 8, 4, 16)), q.new_empty((slots // 4, 8, 16, 4))
 
 
 @_register('attn_modes_store', '(Tensor q, Tensor k, Tensor v, Tensor rhat_op, Tensor rowptr, Tensor col, Tensor? eid, '
@@ -1004,35 +1006,61 @@ def _attn_modes_store(q, k, v, rhat_op, rowptr, col, eid, wpack, bv, rep, layout
     if n_rows * rep != n_dst or layout not in (LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR):
         raise ValueError('n_rows (%d) * rep (%d) != n_dst (%d) or plain layout' % (n_rows, rep, n_dst))
     out = torch.empty(n_dst, C, dtype=torch.float32, device=dev)
-    kk = torch.empty(num_edges, C, dtype=torch.float32, device=dev)
-    vv = torch.empty(num_edges, C, dtype=torch.float32, device=dev)
+    slots = attn_modes_table_slots(num_edges, n_rows)
+    if slots >= (1 << 23):
+        raise ValueError('%d edges: the projection tables address slots by 32-bit byte offsets (< 2^23 slots)' % num_edges)
+    kk = torch.empty(slots // 4, 8, 4, 16, dtype=torch.float32, device=dev)
+    vv = torch.empty(slots // 4, 8, 16, 4, dtype=torch.float32, device=dev)
     fn, name = ((lib.qcn_attn_modes_store_bf16, 'qcn_attn_modes_store_bf16') if bf16
                 else (lib.qcn_attn_modes_store_f32, 'qcn_attn_modes_store_f32'))
     # algorithmic bytes: the fused form's reads + the two projection rows written per edge
     tok = _prof_begin(PROF_ATTN_FUSED, ((1296.0 if bf16 else 1552.0) + 1024.0) * num_edges + 1024.0 * n_dst, dev)
     _lib.check(fn(_ptr(q), _ptr(k), _ptr(v), _ptr(rhat_op), _ptr(rowptr), _ptr(col), _ptr(eid), _ptr(wpack), _ptr(bv), n_dst,
                   n_src, n_rows, num_edges, rhat_op.size(0), int(rep), int(layout), int(col_shift), _ptr(out), _ptr(kk),
-                  _ptr(vv), _stream(dev)), name)
+                  _ptr(vv), slots, _stream(dev)), name)
     _prof_end(tok, dev)
     return out, kk, vv
 
 
+def attn_modes_table_slots(num_edges: int, n_rows: int) -> int:
+    """qcn_attn_modes_table_slots: slots per head plane of the projection tables (rows start on multiples of four slots)."""
+    return (int(num_edges) + 3 * int(n_rows) + 7) & ~3
+
+
+def attn_modes_table_rows(kk: torch.Tensor, vv: torch.Tensor, rowptr: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """The tables of ``attn_modes_store`` as plain rows ``(kk_e, vv_e)`` [E, 128] in CSR order (tests / debugging: a gather
+    by the slot rule of include/qcnet_hip.h, torch ops only)."""
+    rp = rowptr.long()
+    deg = rp[1:] - rp[:-1]
+    rows = torch.repeat_interleave(torch.arange(deg.numel(), device=rp.device), deg)
+    start = (rp[:-1] + 3 * torch.arange(deg.numel(), device=rp.device) + 3) & ~3
+    j = torch.arange(int(rp[0]), int(rp[-1]), device=rp.device)
+    slot = start[rows] + (j - rp[:-1][rows])
+    kk_rows = kk[slot // 4, :, slot % 4, :].reshape(-1, C)        # [E, head, 16]
+    vv_rows = vv[slot // 4, :, :, slot % 4].reshape(-1, C)
+    return kk_rows, vv_rows
+
+
 def attn_modes_cached(q: torch.Tensor, kk: torch.Tensor, vv: torch.Tensor, rowptr: torch.Tensor, bv: torch.Tensor,
-                      rep: int, layout: int) -> torch.Tensor:
+                      rep: int, layout: int, num_edges: Optional[int] = None) -> torch.Tensor:
     """qcn_attn_modes_cached_f32: the propagate of a mode-replicated relation from the stored per-edge projections of an
     ``attn_modes_store`` call on the same sources, graph and layer (bit-identical to ``attn_modes`` for the same q)."""
-    return _op('attn_modes_cached')(q, kk, vv, rowptr, bv, int(rep), int(layout))
+    if num_edges is None:       # upper bound from the table size (the kernel reads the true count from rowptr)
+        num_edges = max(0, 4 * kk.size(0) - 3 * (rowptr.numel() - 1) - 7)
+    return _op('attn_modes_cached')(q, kk, vv, rowptr, bv, int(rep), int(layout), int(num_edges))
 
 
-@_register('attn_modes_cached', '(Tensor q, Tensor kk, Tensor vv, Tensor rowptr, Tensor bv, int rep, int layout) -> Tensor',
-           lambda q, kk, vv, rowptr, bv, rep, layout: torch.empty_like(q))
-def _attn_modes_cached(q, kk, vv, rowptr, bv, rep, layout):
+@_register('attn_modes_cached', '(Tensor q, Tensor kk, Tensor vv, Tensor rowptr, Tensor bv, int rep, int layout, int num_edges) -> Tensor',
+           lambda q, kk, vv, rowptr, bv, rep, layout, num_edges: torch.empty_like(q))
+def _attn_modes_cached(q, kk, vv, rowptr, bv, rep, layout, num_edges):
     dev = q.device
-    n_dst, num_edges = q.size(0), kk.size(0)
+    n_dst, num_edges, slots = q.size(0), int(num_edges), 4 * kk.size(0)
     n_rows = rowptr.numel() - 1
     _require(q, 'q', torch.float32, dev, (n_dst, C))
-    _require(kk, 'kk', torch.float32, dev, (num_edges, C))
-    _require(vv, 'vv', torch.float32, dev, (num_edges, C))
+    _require(kk, 'kk', torch.float32, dev, (slots // 4, 8, 4, 16))
+    _require(vv, 'vv', torch.float32, dev, (slots // 4, 8, 16, 4))
+    if slots < attn_modes_table_slots(num_edges, n_rows):
+        raise ValueError('tables of %d slots for %d edges in %d rows' % (slots, num_edges, n_rows))
     _require(rowptr, 'rowptr', torch.int32, dev, (n_rows + 1,))
     _require(bv, 'bv', torch.float32, dev, (C,))
     if n_rows * rep != n_dst or layout not in (LAYOUT_MODE_MAJOR, LAYOUT_AGENT_MAJOR):
@@ -1041,7 +1069,7 @@ def _attn_modes_cached(q, kk, vv, rowptr, bv, rep, layout):
     # algorithmic bytes: the two projection rows per edge, q in and out per destination
     tok = _prof_begin(PROF_ATTN_FUSED, 1024.0 * num_edges + 1024.0 * n_dst, dev)
     _lib.check(_lib.lib().qcn_attn_modes_cached_f32(_ptr(q), _ptr(kk), _ptr(vv), _ptr(rowptr), _ptr(bv), n_dst, n_rows,
-                                                   num_edges, int(rep), int(layout), _ptr(out), _stream(dev)),
+                                                   num_edges, slots, int(rep), int(layout), _ptr(out), _stream(dev)),
                'qcn_attn_modes_cached_f32')
     _prof_end(tok, dev)
     return out

@@ -301,8 +301,9 @@ def test_attn_modes_store_and_cached_equal_recomputation(layout, K, n_rows, n_sr
     plain = ops.attn_modes(q.to(DEV), *args)
     out, kk, vv = ops.attn_modes_store(q.to(DEV), *args)
     assert torch.equal(out, plain)
-    assert kk.shape == vv.shape == (E, 128)
+    assert kk.numel() == vv.numel() == 128 * ops.attn_modes_table_slots(E, n_rows)
     if E:
+        kk_rows, vv_rows = ops.attn_modes_table_rows(kk, vv, g.rowptr)     # head-major tables -> [E, 128] rows in CSR order
         rid = (g.eid if g.eid is not None else torch.arange(E, device=DEV)).long()
         wk64, wv64 = (w_kr * gamma[None]).double().to(DEV), (w_vr * gamma[None]).double().to(DEV)
         rh = rhat[rid].bfloat16().double() if bf16 else rhat[rid].double()
@@ -310,8 +311,8 @@ def test_attn_modes_store_and_cached_equal_recomputation(layout, K, n_rows, n_sr
             wk64, wv64 = wk64.float().bfloat16().double(), wv64.float().bfloat16().double()
         want_kk = k.to(DEV).double()[g.col.long()] + rh @ wk64.t()
         want_vv = v.to(DEV).double()[g.col.long()] + rh @ wv64.t()
-        assert rel_err(kk, want_kk) < 5e-6 and rel_err(vv, want_vv) < 5e-6
-    again = ops.attn_modes_cached(q2.to(DEV), kk, vv, g.rowptr, bv, K, layout)
+        assert kk_rows.shape == (E, 128) and rel_err(kk_rows, want_kk) < 5e-6 and rel_err(vv_rows, want_vv) < 5e-6
+    again = ops.attn_modes_cached(q2.to(DEV), kk, vv, g.rowptr, bv, K, layout, E)
     assert torch.equal(again, ops.attn_modes(q2.to(DEV), *args))
     assert torch.equal(ops.attn_modes_cached(q.to(DEV), kk, vv, g.rowptr, bv, K, layout), plain)
 

@@ -229,9 +229,11 @@ def test_op_attn_modes():
     out, kk, vv = op('attn_modes_store')(dev(q), dev(k), dev(v), ops.split_rows(dev(rhat)), rowptr, col, eid,
                                          ops.pack_attn_modes(dev(wk), dev(wv), mode=ops.MATMUL_SPLIT_F16), dev(bv), K,
                                          ops.LAYOUT_AGENT_MAJOR, 0)
-    assert torch.equal(out, got) and kk.shape == vv.shape == (col.numel(), 128)
-    assert rel_err(kk, (k[col.long().cpu()] + kr[eid.long().cpu()])) < 5e-6
-    assert torch.equal(op('attn_modes_cached')(dev(q), kk, vv, rowptr, dev(bv), K, ops.LAYOUT_AGENT_MAJOR), got)
+    assert torch.equal(out, got) and kk.numel() == vv.numel() == 128 * ops.attn_modes_table_slots(col.numel(), rowptr.numel() - 1)
+    kk_rows, vv_rows = ops.attn_modes_table_rows(kk, vv, rowptr)
+    assert rel_err(kk_rows, (k[col.long().cpu()] + kr[eid.long().cpu()])) < 5e-6
+    assert rel_err(vv_rows, (v[col.long().cpu()] + (vr - bv)[eid.long().cpu()])) < 5e-6      # the bias enters in the row epilogue
+    assert torch.equal(op('attn_modes_cached')(dev(q), kk, vv, rowptr, dev(bv), K, ops.LAYOUT_AGENT_MAJOR, col.numel()), got)
 
 
 def test_op_mask_pairs_and_coalesce_max():
