@@ -12,6 +12,7 @@ inside the timed region, as they would for a dataset).  ``--config cfg4`` is the
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import functools
 import json
 import os
 import statistics
@@ -31,7 +32,7 @@ _bootstrap.ensure_package()
 
 from tempenslearnagg_qcnet_amd import ops, sharding  # noqa: E402
 from tempenslearnagg_qcnet_amd.predictors import TempEnsLearnAgg  # noqa: E402
-from tempenslearnagg_qcnet_amd.synthetic import config_scene, make_batch  # noqa: E402
+from tempenslearnagg_qcnet_amd.synthetic import config_scene, make_batch, make_scenario  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
 # MFMA ceilings of the three arithmetic modes, TFLOP/s of fp32-equivalent work (MI355X_MICROARCH.md dense peaks: fp32 matrix
@@ -119,6 +120,7 @@ def main() -> None:
     ap.add_argument('--config', default='cfg3', choices=['cfg3', 'cfg4', 'cfg5', 'tiny'])
     ap.add_argument('--batch', type=int, default=None)
     ap.add_argument('--scenarios', type=int, default=None, help='cfg5: size of the scenario pool (default 10000)')
+    ap.add_argument('--workers', type=int, default=6, help='cfg5: loader worker processes per rank (0: synchronous)')
     ap.add_argument('--matmul', default=None, choices=sorted(MODES), help='default: bf16 for cfg4 (as BASELINE.json names it), '
                     'split (fp32-equivalent) otherwise')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -174,8 +176,12 @@ def main() -> None:
         if pooled:
             n_scen = args.scenarios or 10000
             t0 = time.perf_counter()
+            # batches are built by worker processes ahead of the GPU and arrive in pinned memory (datasets/loader.py: the
+            # reference's DataLoader(num_workers, pin_memory), evaluate.py:42-43); --workers 0 builds them inside the loop
             gathered, sums = sharding.run_sharded(model.predict, lambda ids: make_batch(ids, **cfg['scene']), n_scen, batch_size,
-                                                  rank, world, device, metric_fn=sharding.validation_metric_sums)
+                                                  rank, world, device, metric_fn=sharding.validation_metric_sums,
+                                                  get_scenario=(functools.partial(make_scenario, **cfg['scene'])
+                                                                if args.workers > 0 else None), num_workers=args.workers)
             barrier()
             elapsed = time.perf_counter() - t0
             steps = -(-len(sharding.shard_scenario_ids(n_scen, 0, world)) // batch_size)

@@ -93,6 +93,11 @@ int qcn_csr_build(const int64_t *src, const int64_t *dst, int64_t num_edges, int
  * sort's workspace is a device array that lives inside the library (QCN_CSR_STATIC_SCRATCH_BYTES per GPU the library
  * runs on, held until the process ends) and the call makes no hipMalloc / hipFree or allocating library call.
  *   - num_edges <= QCN_CSR_STATIC_MAX_EDGES (qcn_csr_static_max_edges()), else QCN_ERR_TOO_LARGE and nothing is launched;
+ *     QCN_ERR_TOO_LARGE also when rocPRIM's sort temporaries for this (num_edges, n_dst) exceed the array
+ *     (qcn_csr_workspace_bytes(num_edges, n_dst) > QCN_CSR_STATIC_SCRATCH_BYTES: very large n_dst);
+ *   - set-up: the array's address is looked up once per device (hipGetSymbolAddress under a mutex).  Call
+ *     qcn_csr_static_max_edges() once per device, with that device current, BEFORE a graph capture begins (it performs
+ *     the lookup); without it the first qcn_csr_build_static call on a device does, which must then be outside a capture;
  *   - every call on one GPU shares that GPU's array: calls that overlap on one GPU (two streams, two host threads)
  *     race — serialise them (one stream, or events between them); calls on different GPUs are independent;
  *   - the device current at the call is the one whose array is used: `stream` must belong to it. */

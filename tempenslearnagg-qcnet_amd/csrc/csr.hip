@@ -175,7 +175,13 @@ static unsigned char *csr_static_scratch()
     return g_scratch_ptr[dev];
 }
 
-extern "C" int64_t qcn_csr_static_max_edges(void) { return QCN_CSR_STATIC_MAX_EDGES; }
+// Also the set-up call: resolves the current device's array address (hipGetSymbolAddress + a mutex, neither of which
+// belongs inside a graph capture), so that qcn_csr_build_static itself only reads a cached pointer afterwards.
+extern "C" int64_t qcn_csr_static_max_edges(void)
+{
+    (void)csr_static_scratch();
+    return QCN_CSR_STATIC_MAX_EDGES;
+}
 
 extern "C" int qcn_csr_build_static(const int64_t *src, const int64_t *dst, int64_t num_edges, int64_t n_dst,
                                     int32_t *rowptr, int32_t *col, int32_t *eid, void *stream)

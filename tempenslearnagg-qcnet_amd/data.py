@@ -195,6 +195,11 @@ class HeteroData:
     def cpu(self):
         return self.to('cpu')
 
+    def pin_memory(self):
+        """Every tensor in page-locked host memory (torch's DataLoader calls this on custom batch objects when
+        ``pin_memory=True``): ``to(device, non_blocking=True)`` is then asynchronous."""
+        return self._map(lambda t: t.pin_memory() if not t.is_cuda else t)
+
     def clone(self):
         return self._map(lambda t: t.clone())
 

@@ -143,8 +143,14 @@ validation_metric_sums.width = 2 * len(VALIDATION_METRICS)
 
 def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], object], num_scenarios: int,
                 batch_size: int, rank: int, world_size: int, device,
-                metric_fn: Callable = endpoint_metric_sums, metric_width: int = None) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Runs this rank's shard and returns (all records sorted by scenario id, reduced metric sums).  ``metric_fn(data, pred)``
+                metric_fn: Callable = endpoint_metric_sums, metric_width: int = None,
+                get_scenario: Callable[[int], object] = None, num_workers: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Runs this rank's shard and returns (all records sorted by scenario id, reduced metric sums).
+    Batches: ``make_batch_fn(ids)`` builds one synchronously inside the loop; with ``get_scenario`` (scenario id -> one
+    scenario) instead, ``num_workers`` worker processes build and collate the batches AHEAD of the GPU and hand them over in
+    pinned memory (datasets/loader.py — the reference's ``DataLoader(num_workers, pin_memory)``, evaluate.py:42-43), and the
+    host-to-device copies are asynchronous: the loop never waits for a batch unless the workers are the slower side.
+    ``metric_fn(data, pred)``
     returns the batch's (sum, count) pairs: ``validation_metric_sums`` on the GPU (the reference's seven metrics from the
     HIP kernel); the default is device-agnostic torch arithmetic so the collectives can be exercised over gloo.
     ``metric_width``: length of that vector (default: ``metric_fn.width``) — a rank whose shard is empty
@@ -153,8 +159,15 @@ def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], objec
         metric_width = getattr(metric_fn, 'width', None)
     records = []
     sums = None
-    for ids in batches(shard_scenario_ids(num_scenarios, rank, world_size), batch_size):
-        data = make_batch_fn(ids).to(device)
+    my_ids = shard_scenario_ids(num_scenarios, rank, world_size)
+    if get_scenario is not None:
+        from .datasets.loader import scenario_loader
+        source = scenario_loader(my_ids, get_scenario, batch_size, num_workers=num_workers)
+    else:
+        source = ((ids, make_batch_fn(ids)) for ids in batches(my_ids, batch_size))
+    for ids, cpu_batch in source:
+        ids = [int(i) for i in ids]
+        data = cpu_batch.to(device, non_blocking=True)
         pred = predict_fn(data)
         records.append(focal_records(ids, data, pred))
         part = metric_fn(data, pred).float()

@@ -100,3 +100,28 @@ def test_partition_is_a_disjoint_cover():
         ids = [i for r in range(world) for i in sharding.shard_scenario_ids(10000, r, world)]
         assert sorted(ids) == list(range(10000))
     assert sharding.batches(list(range(7)), 3) == [[0, 1, 2], [3, 4, 5], [6]]
+
+
+def test_worker_loader_equals_synchronous_batches():
+    """datasets/loader.py (worker processes collate ahead, the reference's DataLoader(num_workers), evaluate.py:42-43): the
+    same (ids, batch) sequence as building every batch inside the loop — ragged last batch, an empty shard — and the same
+    records through run_sharded."""
+    import functools
+    from tempenslearnagg_qcnet_amd.datasets import scenario_loader
+    from tempenslearnagg_qcnet_amd.synthetic import make_scenario
+    get = functools.partial(make_scenario, **SCENE_TINY)
+    ids = [5, 0, 3, 9, 11, 2, 7]
+    for workers in (0, 2):
+        seen = list(scenario_loader(ids, get, 3, num_workers=workers, pin_memory=False))
+        assert [[int(i) for i in b[0]] for b in seen] == [[5, 0, 3], [9, 11, 2], [7]]
+        for got_ids, got in seen:
+            want = make_batch([int(i) for i in got_ids], **SCENE_TINY)
+            assert got.num_graphs == want.num_graphs
+            for key in ('agent', 'map_polygon', 'map_point', ('map_point', 'to', 'map_polygon'), ('map_polygon', 'to', 'map_polygon')):
+                for name, v in want[key].items():
+                    if torch.is_tensor(v):
+                        assert torch.equal(got[key][name], v), (key, name)
+    assert list(scenario_loader([], get, 3, num_workers=2)) == []
+    sync = sharding.run_sharded(_fake_predict, lambda i: make_batch(i, **SCENE_TINY), 8, 3, 0, 1, torch.device('cpu'))
+    ahead = sharding.run_sharded(_fake_predict, None, 8, 3, 0, 1, torch.device('cpu'), get_scenario=get, num_workers=2)
+    assert torch.equal(sync[0], ahead[0]) and torch.equal(sync[1], ahead[1])
