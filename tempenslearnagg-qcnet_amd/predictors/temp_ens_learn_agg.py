@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from .. import ops
 from ..metrics import MotionMetrics
 from ..modules import TemporalAggregate
-from ..utils.prep import inputs_ready, record_streams, run_prep
+from ..utils.prep import inputs_ready, record_streams, register_stream, run_prep
 
 _AGG_STREAMS: Dict[tuple, 'torch.cuda.Stream'] = {}     # per (host thread, device), like the preparation stream
 _AGG_LOCK = threading.Lock()
@@ -28,6 +28,7 @@ def _aggregate_stream(device: torch.device) -> 'torch.cuda.Stream':
     with _AGG_LOCK:
         if idx not in _AGG_STREAMS:
             _AGG_STREAMS[idx] = torch.cuda.Stream(device=device)
+            register_stream(device, _AGG_STREAMS[idx])
         return _AGG_STREAMS[idx]
 from .qcnet_sliding import QCNetSliding
 

@@ -137,6 +137,45 @@ def reduce_metric_sums(sums: torch.Tensor, world_size: int) -> torch.Tensor:
     return sums
 
 
+def start_loader(get_scenario: Callable[[int], object], num_scenarios: int, batch_size: int, rank: int, world_size: int,
+                 num_workers: int):
+    """The worker-process loader over this rank's shard (datasets/loader.py); its workers start building batches at once."""
+    from .datasets.loader import scenario_loader
+    return scenario_loader(shard_scenario_ids(num_scenarios, rank, world_size), get_scenario, batch_size, num_workers=num_workers)
+
+
+_COPY_STREAMS: Dict[tuple, 'torch.cuda.Stream'] = {}
+
+
+def to_device_ahead(cpu_batch, device):
+    """The device copy of a (pinned) batch, made on a COPY stream of its own: the copies do not queue behind the kernels
+    of the previous step, so the batch's ready mark (``data.mark_ready``, recorded on the copy stream) fires while that
+    step still runs and the graph preparation of this batch (utils/prep.py) overlaps it — with the copies on the main
+    stream the preparation could only start when the previous step had finished (cfg5: 685 -> scenarios/s, see DESIGN).
+    The current stream waits for the mark; the tensors are marked as used on it and on the path's other streams
+    (``prep.consumer_streams``), because their memory belongs to the copy stream's pool."""
+    device = torch.device(device)
+    if device.type != 'cuda':
+        return cpu_batch.to(device)
+    import threading
+    from .utils import prep
+    key = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
+    copy = _COPY_STREAMS.get(key)
+    if copy is None:
+        copy = _COPY_STREAMS[key] = torch.cuda.Stream(device=device)
+    main = torch.cuda.current_stream(device)
+    with torch.cuda.stream(copy):
+        data = cpu_batch.to(device, non_blocking=True)          # records the ready mark on the copy stream
+    for stream in [main] + prep.consumer_streams(device):
+        prep.record_streams(data, stream)
+    event = data.ready_event() if hasattr(data, 'ready_event') else None
+    if event is not None:
+        main.wait_event(event)
+    else:
+        main.wait_stream(copy)
+    return data
+
+
 endpoint_metric_sums.width = 6
 validation_metric_sums.width = 2 * len(VALIDATION_METRICS)
 
@@ -144,12 +183,14 @@ validation_metric_sums.width = 2 * len(VALIDATION_METRICS)
 def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], object], num_scenarios: int,
                 batch_size: int, rank: int, world_size: int, device,
                 metric_fn: Callable = endpoint_metric_sums, metric_width: int = None,
-                get_scenario: Callable[[int], object] = None, num_workers: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
+                get_scenario: Callable[[int], object] = None, num_workers: int = 0, loader=None) -> Tuple[torch.Tensor, torch.Tensor]:
     """Runs this rank's shard and returns (all records sorted by scenario id, reduced metric sums).
     Batches: ``make_batch_fn(ids)`` builds one synchronously inside the loop; with ``get_scenario`` (scenario id -> one
     scenario) instead, ``num_workers`` worker processes build and collate the batches AHEAD of the GPU and hand them over in
     pinned memory (datasets/loader.py — the reference's ``DataLoader(num_workers, pin_memory)``, evaluate.py:42-43), and the
     host-to-device copies are asynchronous: the loop never waits for a batch unless the workers are the slower side.
+    ``loader``: an already started ``start_loader(...)`` iterator for this rank's shard (workers that outlive one run, the
+    reference's ``persistent_workers=True``) instead of starting one here.
     ``metric_fn(data, pred)``
     returns the batch's (sum, count) pairs: ``validation_metric_sums`` on the GPU (the reference's seven metrics from the
     HIP kernel); the default is device-agnostic torch arithmetic so the collectives can be exercised over gloo.
@@ -160,14 +201,15 @@ def run_sharded(predict_fn: Callable, make_batch_fn: Callable[[List[int]], objec
     records = []
     sums = None
     my_ids = shard_scenario_ids(num_scenarios, rank, world_size)
-    if get_scenario is not None:
-        from .datasets.loader import scenario_loader
-        source = scenario_loader(my_ids, get_scenario, batch_size, num_workers=num_workers)
+    if loader is not None:
+        source = loader
+    elif get_scenario is not None:
+        source = start_loader(get_scenario, num_scenarios, batch_size, rank, world_size, num_workers)
     else:
         source = ((ids, make_batch_fn(ids)) for ids in batches(my_ids, batch_size))
     for ids, cpu_batch in source:
         ids = [int(i) for i in ids]
-        data = cpu_batch.to(device, non_blocking=True)
+        data = to_device_ahead(cpu_batch, device)
         pred = predict_fn(data)
         records.append(focal_records(ids, data, pred))
         part = metric_fn(data, pred).float()

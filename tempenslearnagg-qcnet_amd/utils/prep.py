@@ -86,6 +86,26 @@ def _record(obj, stream, seen) -> None:
                 _record(v, stream, seen)
 
 
+_extra: Dict[tuple, list] = {}
+
+
+def register_stream(device: torch.device, stream: 'torch.cuda.Stream') -> None:
+    """Another stream of this host thread that reads a batch's input tensors (the predictor's aggregate stream)."""
+    idx = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
+    with _side_lock:
+        if stream not in _extra.setdefault(idx, []):
+            _extra[idx].append(stream)
+
+
+def consumer_streams(device: torch.device) -> list:
+    """Every stream of this host thread on which the path may read the input tensors of a batch besides the current one:
+    the preparation stream and the registered ones.  A loader that allocates the device copy of a batch on a COPY stream
+    marks the tensors as used on these (``record_streams``) so that the allocator does not hand their memory to the next
+    copy while kernels of an earlier step still read it."""
+    idx = (threading.get_ident(), device.index if device.index is not None else torch.cuda.current_device())
+    return [side_stream(device)] + list(_extra.get(idx, []))
+
+
 def record_streams(obj, stream) -> None:
     """Public form of the walk above: every GPU tensor reachable from ``obj`` (dicts, lists, objects) is marked as used on
     ``stream`` for the caching allocator — for results produced on one stream and consumed on another."""
