@@ -351,6 +351,23 @@ int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const f
                 const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, int matmul_mode,
                 void *stream);
 
+/* The trajectory re-encoding (modules/qcnet_decoder.py:255-257) with the GRU's input halves handed over in the RECURRENCE'S
+ * own layout — no counterpart in the reference (there y_emb's output, a transpose and cuDNN's GRU).
+ *   qcn_fourier_gru_input_f32 = qcn_fourier_linear_f32 / qcn_fourier_folded_linear_f32 (folded != 0) with n_out = 3 on rows
+ *     x[seq * n_steps + t] (x: [n_seq * n_steps, input_dim]), but a wave's tile is ONE step of 32 consecutive sequences and
+ *     the outputs are blocked:  gi_g[((seq / 32) * n_steps + t) * 4096 + ((4 w + q) * 64 + lane) * 4 + i]  holds feature
+ *     32 w + 8 q + 4 (lane / 32) + i of sequence 32 (seq / 32) + lane % 32 at step t — each gi_g has
+ *     qcn_gru_blocked_rows(n_seq, n_steps) * 128 floats (the last sequence block is padded to 32; padding is written);
+ *   qcn_gru_blocked_f32 = qcn_gru_f32 in the split-f16 arithmetic (whh = its split pack) reading that layout: the twelve
+ *     loads of a step are contiguous 1 KiB pieces per wave (row-major gi: 32-byte pieces of 32 rows each), and the producer
+ *     stores straight from its accumulator registers.  Same values, bit for bit, as the row-major pair of calls. */
+int64_t qcn_gru_blocked_rows(int64_t n_seq, int n_steps);
+int qcn_fourier_gru_input_f32(const float *x, int input_dim, const float *pack, int64_t n_seq, int n_steps,
+                              const float *wt, const float *bias, int folded, float *gi_r, float *gi_z, float *gi_n,
+                              int matmul_mode, void *stream);
+int qcn_gru_blocked_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh_pack,
+                        const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, void *stream);
+
 /* K6 — y = (x - mean) / sqrt(var + eps) per 128-wide row (LayerNorm without affine; the layer-independent half
  * of attn_prenorm_r, layers/attention_layer.py:63,82). */
 int qcn_row_normalize_f32(const float *x, float *y, int64_t n_rows, float eps, void *stream);

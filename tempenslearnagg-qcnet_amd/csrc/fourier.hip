@@ -67,6 +67,13 @@ struct FourierTail {
     float *y[3];
     int n_out;            // 0: store the embedding itself
     int fold;             // 1: the caller folded to_out's Linear into wt / bias (y_j = W'_j relu(LN(sum)) + b'_j): one GEMM less
+    // GRU-input form (qcn_fourier_gru_input_f32): rows are (sequence, step) pairs, row = seq * gru_steps + step, and a wave's
+    // tile is ONE step of 32 consecutive sequences (tile = seq_block * gru_steps + step) instead of 32 consecutive rows; the
+    // outputs y[j] are written in the register layout itself — [tile][feature block 4][q 4][lane 64][4 floats], which is
+    // exactly what lane (n, h) of wave `feature block` of qcn_gru_blocked_f32 consumes for that step: every store (and every
+    // load of the recurrence) is a contiguous 1 KiB per wave, and the three LDS transpositions per tile disappear.
+    int gru_steps;        // 0: plain row-major outputs
+    int64_t n_seq;
 };
 
 template <int IN, int MODE, int WAVES>
@@ -83,9 +90,20 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     f32x4 *const xpose = wlds + 2 * kMatVec4 + kVecBlock / 4 + (threadIdx.x >> 6) * 128;   // store_tile2: coalesced row stores
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
-    const bool valid = row < n_rows;
-    const int64_t rowc = valid ? row : n_rows - 1;   // tail lanes recompute the last row; their store is masked
+    int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
+    bool valid = row < n_rows;
+    int64_t rowc = valid ? row : n_rows - 1;   // tail lanes recompute the last row; their store is masked
+    int64_t gru_tile = -1;                     // GRU-input form: this wave's (sequence block, step) tile; -1: none / beyond the end
+    if (tail.gru_steps > 0) {
+        const int64_t n_tiles = ((tail.n_seq + kRowsPerWave - 1) / kRowsPerWave) * tail.gru_steps;
+        const int64_t tile = (int64_t)blockIdx.x * WAVES + wave;
+        const int64_t tc = tile < n_tiles ? tile : n_tiles - 1;
+        const int64_t seq = (tc / tail.gru_steps) * kRowsPerWave + (lane & 31);
+        rowc = (seq < tail.n_seq ? seq : tail.n_seq - 1) * tail.gru_steps + tc % tail.gru_steps;   // sequences past the end: the last one again
+        row = rowc;
+        valid = true;
+        gru_tile = tile < n_tiles ? tile : -1;
+    }
     const float eps = 1e-5f;
     const float *mats = pack;
     const float *vecs = svec;
@@ -207,7 +225,22 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
                     j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr,
                     wlds + ((j + first_buf + 1) & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
-        store_tile2(acc, tail.y[j], row0, n_rows, xpose, lane);
+        if (tail.gru_steps > 0) {
+            if (gru_tile >= 0) {            // (uniform per wave) the padding sequences of the last block are written too
+                float *dst = tail.y[j] + gru_tile * (int64_t)(kRowsPerWave * kC) + lane * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = acc[t][4 * q + i];
+                        *reinterpret_cast<f32x4 *>(dst + (4 * t + q) * 256) = v;
+                    }
+            }
+        } else {
+            store_tile2(acc, tail.y[j], row0, n_rows, xpose, lane);
+        }
     }
     skew_end(skew);
 }
@@ -312,8 +345,10 @@ static int launch_fourier(const float *x, int input_dim, const float *extra, int
 #endif
         return hipGetLastError() == hipSuccess ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
     }
-    const int waves = pick_waves(n_rows, 1.5);
-    const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    // (GRU-input form: one tile per (sequence block, step), the last sequence block padded to 32)
+    const int64_t tile_rows = tail.gru_steps > 0 ? ((tail.n_seq + 31) / 32) * 32 * tail.gru_steps : n_rows;
+    const int waves = pick_waves(tile_rows, 1.5);
+    const unsigned grid = (unsigned)((tile_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
 #define QCN_LAUNCH(S, W)                                                                                           \
     hipLaunchKernelGGL((fourier_kernel<QCN_IN, S, W>), dim3(grid), dim3(64 * W), 0, s, x, extra, (int)extra_div, pack, y, \
@@ -364,7 +399,7 @@ extern "C" int qcn_fourier_linear_f32(const float *x, int input_dim, const float
                                       float *y0, float *y1, float *y2, int matmul_mode, void *stream)
 {
     if (n_out < 1 || n_out > 3 || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
-    FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 0};
+    FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 0, 0, 0};
     return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, matmul_mode, stream);
 }
 
@@ -374,6 +409,23 @@ extern "C" int qcn_fourier_folded_linear_f32(const float *x, int input_dim, cons
 {
     if (n_out < 1 || n_out > 3 || !wt || !y0 || (n_out > 1 && !y1) || (n_out > 2 && !y2)) return QCN_ERR_INVALID_ARGUMENT;
     if (input_dim < 1) return QCN_ERR_UNSUPPORTED;   // the last in-loop GEMM stages the first folded matrix
-    FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 1};
+    FourierTail tail{wt, bias, {y0, y1, y2}, n_out, 1, 0, 0};
     return launch_fourier(x, input_dim, extra, extra_div, pack, n_rows, 0, nullptr, tail, matmul_mode, stream);
+}
+
+extern "C" int64_t qcn_gru_blocked_rows(int64_t n_seq, int n_steps)
+{
+    return n_seq < 0 || n_steps < 1 ? -1 : ((n_seq + 31) / 32) * 32 * (int64_t)n_steps;
+}
+
+extern "C" int qcn_fourier_gru_input_f32(const float *x, int input_dim, const float *pack, int64_t n_seq, int n_steps,
+                                         const float *wt, const float *bias, int folded, float *gi_r, float *gi_z, float *gi_n,
+                                         int matmul_mode, void *stream)
+{
+    if (n_seq < 0 || n_steps < 1 || !wt || !gi_r || !gi_z || !gi_n) return QCN_ERR_INVALID_ARGUMENT;
+    if (input_dim < 1) return QCN_ERR_UNSUPPORTED;
+    if (n_seq == 0) return QCN_OK;
+    FourierTail tail{wt, bias, {gi_r, gi_z, gi_n}, 3, folded ? 1 : 0, n_steps, n_seq};
+    // (the two-tile kernel is never taken: a tail with outputs keeps the one-tile form, see launch_fourier)
+    return launch_fourier(x, input_dim, nullptr, 1, pack, n_seq * n_steps, 0, nullptr, tail, matmul_mode, stream);
 }

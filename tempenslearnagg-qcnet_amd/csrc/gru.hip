@@ -118,6 +118,10 @@ __device__ __forceinline__ float fast_tanh(float x)
     return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
 
+// BLOCKED: the input halves come in the layout qcn_fourier_gru_input_f32 writes — [sequence block][step][wave 4][q 4][lane 64]
+// [4 floats] per gate — so that the twelve loads of a step are twelve contiguous 1 KiB pieces per wave instead of 32-byte
+// pieces of 32 different rows each.
+template <bool BLOCKED>
 __global__ __launch_bounds__(256) void gru_split_kernel(const float *__restrict__ gi_r, const float *__restrict__ gi_z,
                                                         const float *__restrict__ gi_n, const float *__restrict__ wpack,
                                                         const float *__restrict__ b_hh, const float *__restrict__ h0,
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(256) void gru_split_kernel(const float *__restrict_
     auto request = [&](int t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const size_t off = (size_t)(grow + t) * kC + 32 * wave + 8 * q + 4 * hh;
+            const size_t off = BLOCKED ? ((size_t)blockIdx.x * n_steps + t) * (kRowsPerWave * kC) + ((4 * wave + q) * 64 + lane) * 4
+                                       : (size_t)(grow + t) * kC + 32 * wave + 8 * q + 4 * hh;
             gnx[0][q] = *reinterpret_cast<const f32x4 *>(gi_r + off);
             gnx[1][q] = *reinterpret_cast<const f32x4 *>(gi_z + off);
             gnx[2][q] = *reinterpret_cast<const f32x4 *>(gi_n + off);
@@ -248,10 +253,23 @@ extern "C" int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi
     hipStream_t s = qcn_stream(stream);
     const unsigned grid = (unsigned)((n_seq + kRowsPerWave - 1) / kRowsPerWave);
     if (matmul_mode == QCN_MATMUL_SPLIT_F16)
-        hipLaunchKernelGGL(gru_split_kernel, dim3(grid), dim3(256), 0, s, gi_r, gi_z, gi_n, whh_t, b_hh, h0, n_seq, n_steps,
+        hipLaunchKernelGGL(gru_split_kernel<false>, dim3(grid), dim3(256), 0, s, gi_r, gi_z, gi_n, whh_t, b_hh, h0, n_seq, n_steps,
                            h_out);
     else
         hipLaunchKernelGGL(gru_kernel, dim3(grid), dim3(256), 0, s, gi_r, gi_z, gi_n, whh_t, b_hh, h0, n_seq, n_steps, h_out);
+    QCN_CHECK_LAUNCH();
+    return QCN_OK;
+}
+
+extern "C" int qcn_gru_blocked_f32(const float *gi_r, const float *gi_z, const float *gi_n, const float *whh_pack,
+                                   const float *b_hh, const float *h0, int64_t n_seq, int n_steps, float *h_out, void *stream)
+{
+    if (n_seq < 0 || n_steps < 1) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_seq == 0) return QCN_OK;
+    if (!gi_r || !gi_z || !gi_n || !whh_pack || !b_hh || !h0 || !h_out) return QCN_ERR_INVALID_ARGUMENT;
+    const unsigned grid = (unsigned)((n_seq + kRowsPerWave - 1) / kRowsPerWave);
+    hipLaunchKernelGGL(gru_split_kernel<true>, dim3(grid), dim3(256), 0, qcn_stream(stream), gi_r, gi_z, gi_n, whh_pack, b_hh, h0,
+                       n_seq, n_steps, h_out);
     QCN_CHECK_LAUNCH();
     return QCN_OK;
 }

@@ -22,6 +22,9 @@ from ..utils.weight_init import weight_init
 from ..utils.prep import run_prep
 from ._common import node_ptr, rel_geometry
 
+# the GRU's input halves in the recurrence's own blocked layout (ops.trajectory_gru); QCN_BLOCKED_GRU=0: row-major, for A/B runs
+BLOCKED_GRU_INPUT = os.environ.get('QCN_BLOCKED_GRU', '1') != '0'
+
 
 class QCNetDecoder(nn.Module):
 
@@ -297,9 +300,13 @@ class QCNetDecoder(nn.Module):
         # trajectory re-encoding: Fourier embedding of the proposed way-points, GRU over the Tf steps, last hidden state
         # (reference :255-257); row n * Tf + t of the embedding is step t of mode query n
         wih_t, b_ih, whh, b_hh, h0, mm_mode, fold = self._gru_packs()
-        gi = ops.fourier_linear(y_in.reshape(-1, y_dim).contiguous().float(), y_dim,
-                                self.y_emb.packed_weights(), wih_t, b_ih, folded=fold, mode=mm_mode)   # y_emb + the GRU's input half, one launch
-        m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0, mode=mm_mode)
+        y_rows = y_in.reshape(-1, y_dim).contiguous().float()
+        if mm_mode != ops.MATMUL_EXACT_F32 and BLOCKED_GRU_INPUT:
+            # y_emb + the GRU's input half + the recurrence, the input halves in the recurrence's own layout (two launches)
+            m = ops.trajectory_gru(y_rows, y_dim, Tf, self.y_emb.packed_weights(), wih_t, b_ih, fold, whh, b_hh, h0, mode=mm_mode)
+        else:
+            gi = ops.fourier_linear(y_rows, y_dim, self.y_emb.packed_weights(), wih_t, b_ih, folded=fold, mode=mm_mode)
+            m = ops.gru_recurrence(gi[0], gi[1], gi[2], Tf, whh, b_hh, h0, mode=mm_mode)
         return dict(m=m, graphs=graphs, loc_propose_pos=loc_propose_pos, scale_propose_pos=scale_propose_pos,
                     loc_propose_head=loc_propose_head, conc_propose_head=conc_propose_head, A=A,
                     edges=(ei_pl2m_1, ei_t2m, ei_pl2m, ei_a2m, ei_m2m))

@@ -529,6 +529,49 @@ def _fourier_linear(x, input_dim, pack, wt, bias, folded, mode):
     return ys
 
 
+def trajectory_gru(x: torch.Tensor, input_dim: int, n_steps: int, pack: torch.Tensor, wt: torch.Tensor, bias: torch.Tensor,
+                   folded: bool, whh_pack: torch.Tensor, b_hh: torch.Tensor, h0: torch.Tensor, mode: Optional[int] = None
+                   ) -> torch.Tensor:
+    """The decoder's trajectory re-encoding (modules/qcnet_decoder.py:255-257) as two launches that hand the GRU's input
+    halves over in the recurrence's own blocked layout (qcn_fourier_gru_input_f32 + qcn_gru_blocked_f32): same values as
+    ``fourier_linear`` + ``gru_recurrence``, bit for bit.  ``x`` [n_seq * n_steps, input_dim], row = seq * n_steps + t;
+    split-f16 / bf16 modes only (the exact mode's recurrence kernel has another thread mapping)."""
+    return _op('trajectory_gru')(x, int(input_dim), int(n_steps), pack, wt, bias, bool(folded), whh_pack, b_hh, h0, _mode(mode))
+
+
+@_register('trajectory_gru', '(Tensor x, int input_dim, int n_steps, Tensor pack, Tensor wt, Tensor bias, bool folded, Tensor whh_pack, '
+           'Tensor b_hh, Tensor h0, int mode) -> Tensor',
+           lambda x, input_dim, n_steps, pack, wt, bias, folded, whh_pack, b_hh, h0, mode: x.new_empty((x.size(0) // n_steps, C)))
+def _trajectory_gru(x, input_dim, n_steps, pack, wt, bias, folded, whh_pack, b_hh, h0, mode):
+    dev = pack.device
+    lib = _lib.lib()
+    if mode == MATMUL_EXACT_F32:
+        raise ValueError('trajectory_gru: split-f16 / bf16 modes only')
+    _require(x, 'x', torch.float32, dev, (None, input_dim))
+    if n_steps < 1 or x.size(0) % n_steps:
+        raise ValueError('x rows (%d) not a multiple of n_steps (%d)' % (x.size(0), n_steps))
+    n_seq = x.size(0) // n_steps
+    _require(pack, 'pack', torch.float32, dev, (int(lib.qcn_fourier_pack_floats(int(input_dim))),))
+    _require(wt, 'wt', torch.float32, dev, (3 * (C * C + 2),))
+    _require(bias, 'bias', torch.float32, dev, (3, C))
+    _require(whh_pack, 'whh_pack', torch.float32, dev, (int(lib.qcn_gru_pack_floats()),))
+    _require(b_hh, 'b_hh', torch.float32, dev, (3 * C,))
+    _require(h0, 'h0', torch.float32, dev, (C,))
+    h = torch.empty(n_seq, C, dtype=torch.float32, device=dev)
+    if n_seq == 0:
+        return h
+    rows = int(lib.qcn_gru_blocked_rows(n_seq, int(n_steps)))
+    gi = torch.empty(3, rows, C, dtype=torch.float32, device=dev)
+    tok = _prof_begin(PROF_FOURIER, _fourier_flops(x.size(0), input_dim, 3 + (0 if folded else 1)), dev)
+    _lib.check(lib.qcn_fourier_gru_input_f32(_ptr(x), int(input_dim), _ptr(pack), n_seq, int(n_steps), _ptr(wt), _ptr(bias),
+                                             int(bool(folded)), _ptr(gi[0]), _ptr(gi[1]), _ptr(gi[2]), int(mode), _stream(dev)),
+               'qcn_fourier_gru_input_f32')
+    _prof_end(tok, dev)
+    _lib.check(lib.qcn_gru_blocked_f32(_ptr(gi[0]), _ptr(gi[1]), _ptr(gi[2]), _ptr(whh_pack), _ptr(b_hh), _ptr(h0), n_seq,
+                                       int(n_steps), _ptr(h), _stream(dev)), 'qcn_gru_blocked_f32')
+    return h
+
+
 def fold_linear(weights, biases, w_inner: torch.Tensor, b_inner: torch.Tensor):
     """(W_j W_inner, W_j b_inner + b_j) for a stack of Linear layers applied to the output of Linear(w_inner, b_inner)
     with nothing in between; products in fp64, results fp32."""

@@ -378,3 +378,42 @@ def test_attention_layer_vs_oracle_in_both_matmul_modes(mode, restore_matmul_mod
     ops.set_matmul_mode(mode)
     test_attention_layer_vs_oracle(True, True)
     test_attention_layer_vs_oracle(False, True)
+
+
+@pytest.mark.parametrize('n_seq,in_dim,folded,mode', [(77, 2, True, 1), (64, 2, False, 1), (1, 3, True, 1), (300, 2, False, 2),
+                                                      (33, 3, True, 2)])
+def test_trajectory_gru_blocked_layout_equals_row_major(n_seq, in_dim, folded, mode, restore_matmul_mode):
+    """ops.trajectory_gru (qcn_fourier_gru_input_f32 + qcn_gru_blocked_f32: the GRU's input halves in the recurrence's own
+    blocked layout, a tile = one step of 32 sequences) against ops.fourier_linear + ops.gru_recurrence (row-major input halves)
+    — the same arithmetic on the same values, so BIT-IDENTICAL; ragged sequence counts (padding of the last block), one
+    sequence, both tail forms, split and bf16 modes."""
+    from tempenslearnagg_qcnet_amd.layers import FourierEmbedding
+    ops.set_matmul_mode(mode)
+    torch.manual_seed(5)
+    n_steps = 60
+    emb = FourierEmbedding(input_dim=in_dim, hidden_dim=128, num_freq_bands=64).eval().to(DEV)
+    with torch.no_grad():
+        for name, p in emb.named_parameters():
+            if p.dim() == 1:
+                p.add_(torch.randn_like(p) * 0.1)
+    gru = torch.nn.GRU(128, 128).eval().to(DEV)
+    with torch.no_grad():
+        for p in gru.parameters():
+            p.copy_(torch.randn_like(p) * 0.12)
+    h0 = torch.randn(128, device=DEV) * 0.3
+    x = torch.randn(n_seq * n_steps, in_dim, device=DEV) * 20.0
+    ws, bs = list(gru.weight_ih_l0.detach().view(3, 128, 128)), list(gru.bias_ih_l0.detach().view(3, 128))
+    with torch.no_grad():
+        if folded:
+            lin = emb.to_out[2]
+            ws, bs = ops.fold_linear(ws, bs, lin.weight, lin.bias)
+        else:
+            bs = torch.stack(bs).contiguous()
+        wt = ops.pack_chain_matrices(ws, mode=mode)
+        whh = ops.pack_gru_whh(gru.weight_hh_l0.detach(), h0, mode=mode)
+        b_hh = gru.bias_hh_l0.detach().contiguous()
+        gi = ops.fourier_linear(x, in_dim, emb.packed_weights(), wt, bs, folded=folded, mode=mode)
+        want = ops.gru_recurrence(gi[0], gi[1], gi[2], n_steps, whh, b_hh, h0, mode=mode)
+        got = ops.trajectory_gru(x, in_dim, n_steps, emb.packed_weights(), wt, bs, folded, whh, b_hh, h0, mode=mode)
+    assert got.shape == (n_seq, 128) and bool(torch.isfinite(got).all())
+    assert torch.equal(got, want)
