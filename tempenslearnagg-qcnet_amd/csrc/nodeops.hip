@@ -12,7 +12,7 @@
 // LayerNorm / sigmoid / residual is an in-lane epilogue, the 512-wide FFN hidden layer is produced and consumed in
 // four 128-wide blocks and never leaves the registers.  HBM traffic per row: reads of agg, xn, s, x and one write
 // (2.5 KiB) against 11 x 32 KiB of flops: MFMA-bound (fp32 matrix cores, exact fp32 fma chains).
-#include "chain_tile.hip.h"
+#include "chain_pair.hip.h"
 #include <cstdio>
 
 namespace {
@@ -85,6 +85,103 @@ __device__ unsigned long long g_post_stamps[2][4];
 #else
 #define PSTAMP(k)
 #endif
+
+
+// ---- feed-forward block with the hidden blocks software-pipelined INSIDE a tile (blocks of up to four waves: one wave per
+// SIMD, 512 registers).  The four first-layer GEMMs W1_hb read the same operand and do not depend on each other, so the
+// epilogue of hidden block hb (bias, ReLU, row maximum, operand split: vector ALU) is cut into steps and issued between
+// the MFMAs of the NEXT block's first-layer GEMM instead of behind its own:
+//     W1_0 | W1_1 + E_0 | W2_0 | W1_2 + E_1 | W2_1 | W1_3 + E_2 | W2_2 | E_3 | W2_3
+// Same arithmetic, element for element, as gemm_add -> ReLU -> make_operand of the sequential form (bit-identical rows).
+struct HidSteps {
+    float mx[4];
+    float red, red2, sc;
+    f32x4 b0, b1;
+};
+
+// LDS reads of step g (issued one slot ahead): the bias groups 2 g, 2 g + 1
+__device__ __forceinline__ void hid_load(HidSteps &S, const float *bias, int h, int g)
+{
+    if (g < 8) {
+        S.b0 = lds_vec4(bias, (2 * g) >> 2, (2 * g) & 3, h);
+        S.b1 = lds_vec4(bias, (2 * g + 1) >> 2, (2 * g + 1) & 3, h);
+    }
+}
+
+// steps 0..7: y = relu(a * U + b) (two groups per step) and four running maxima; 8, 9: row maximum -> power-of-two scale
+// (make_operand's rule); 10..25: one group per step scaled and split into the operand
+__device__ __forceinline__ void hid_step(f32x16 (&a)[4], float U, Operand<kModeSplit> &hid, HidSteps &S, int g, const f32x4 c0,
+                                         const f32x4 c1)
+{
+    if (g < 8) {
+        if (g == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) S.mx[k] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = 2 * g + i, t = m >> 2, q = m & 3;
+            const f32x4 c = i ? c1 : c0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float y = fmaxf(fmaf(a[t][4 * q + k], U, c[k]), 0.f);
+                pin(y);
+                a[t][4 * q + k] = y;
+                S.mx[k] = fmaxf(S.mx[k], y);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pin(S.mx[k]);
+    } else if (g == 8) {
+        S.red = fmaxf(fmaxf(S.mx[0], S.mx[1]), fmaxf(S.mx[2], S.mx[3]));
+        S.red2 = xhalf(S.red);
+    } else if (g == 9) {
+        const float m = fmaxf(S.red, S.red2);
+        int eb = (__builtin_bit_cast(int, m) >> 23) & 0xff;
+        eb = eb < 64 ? 64 : (eb > 190 ? 190 : eb);
+        hid.sc = __builtin_bit_cast(float, (268 - eb) << 23);
+        hid.usc = __builtin_bit_cast(float, (eb - 14) << 23);
+        S.sc = hid.sc;
+    } else if (g < 26) {
+        const int m = g - 10, t = m >> 2, q = m & 3;
+        put4(hid, t, q, grp(a, t, q) * S.sc);
+    }
+}
+
+// acc += W in with the accumulators left in the operands' scale (gemm_raw), `load(g + 1)` and `step(g, b0, b1)` issued in
+// slot g = 0..31 (chain_pair.hip.h's slot layout: first MFMA, the fragment reads two slots ahead, the LDS-DMA pieces of the
+// next matrix and the step's LDS reads in one scheduling region; the step's vector work around the other two MFMAs).
+template <int WAVES, typename Load, typename Step>
+__device__ __forceinline__ void gemm_steps(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w, int lane,
+                                           const float *__restrict__ next, f32x4 *next_dst, int wave, HidSteps &S, Load load,
+                                           Step step)
+{
+    constexpr int kPieces = (kMatVec4 / 64) / WAVES;       // 16 (four waves) / 32 (two)
+    constexpr int kPerSlot = kPieces > 32 ? kPieces / 32 : 1;
+    constexpr int kEvery = kPieces >= 32 ? 1 : 32 / kPieces;
+    f32x4 nh = w[lane], nl = w[64 + lane], nh2 = w[2 * 64 + lane], nl2 = w[3 * 64 + lane];
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {            // g = 4 j + t
+        const int j = g >> 2, t = g & 3;
+        const half8 ah = __builtin_bit_cast(half8, nh), al = __builtin_bit_cast(half8, nl);
+        nh = nh2;
+        nl = nl2;
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], acc[t], 0, 0, 0);
+        if (g + 2 < 32) { nh2 = w[(2 * (g + 2)) * 64 + lane]; nl2 = w[(2 * (g + 2) + 1) * 64 + lane]; }
+        if (g % kEvery == 0) {
+#pragma unroll
+            for (int i = 0; i < kPerSlot; ++i) stage_piece<WAVES, kModeSplit>(next, next_dst, wave, lane, (g / kEvery) * kPerSlot + i);
+        }
+        const f32x4 c0 = S.b0, c1 = S.b1;
+        load(g + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.lo[j], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, in.hi[j], acc[t], 0, 0, 0);
+        step(g, c0, c1);
+        slot_pattern<2, 8>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 template <int MODE, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__restrict__ agg,
@@ -181,6 +278,54 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     make_operand(op, acc);
     f32x16 acc_o[4];
     load_feature_vec(acc_o, vec + kVB2, h);
+    constexpr bool kPipelined = MODE == kModeSplit && WAVES <= 4;
+    if constexpr (kPipelined) {
+        auto W1 = [&](int hb) { return mats + (size_t)(3 + 2 * hb) * kMatFloats; };
+        auto W2 = [&](int hb) { return mats + (size_t)(4 + 2 * hb) * kMatFloats; };
+        auto U1 = [&](int hb) { return op.usc * msc[2 * (3 + 2 * hb) + 1]; };
+        f32x16 a0[4], a1[4];
+        Operand<MODE> hid;
+        HidSteps S;
+        // first-layer GEMM of block hb into `an` (from buffer `wb`), the epilogue of block hb - 1 (accumulators `ap`) between
+        // its MFMAs; stages `nx` into the other buffer
+        auto g1_with_e = [&](f32x16 (&an)[4], f32x16 (&ap)[4], int hb, f32x4 *wb, const float *nx, f32x4 *nb) {
+            const float *bias = vec + kVB1 + (hb - 1) * kC;
+            const float U = U1(hb - 1);
+            fill_zero(an);
+            hid_load(S, bias, h, 0);
+            PSTAMP(0) sync_for_stage(); PSTAMP(1)
+            gemm_steps<WAVES>(an, op, wb, lane, nx, nb, wave, S, [&](int g) { hid_load(S, bias, h, g); },
+                              [&](int g, const f32x4 c0, const f32x4 c1) { hid_step(ap, U, hid, S, g, c0, c1); });
+            PSTAMP(2)
+        };
+        auto g2 = [&](int hb, f32x4 *wb, const float *nx, f32x4 *nb) {
+            PSTAMP(0) sync_for_stage(); PSTAMP(1)
+            gemm<WAVES>(acc_o, hid, wb, msc + 2 * (4 + 2 * hb), lane, nx, nb, wave);
+            PSTAMP(2)
+        };
+        fill_zero(a0);
+        PSTAMP(0) sync_for_stage(); PSTAMP(1)
+        gemm_raw<WAVES, MODE>(a0, op, buf1, lane, W1(1), buf0, wave);                 // W1_0
+        PSTAMP(2)
+        g1_with_e(a1, a0, 1, buf0, W2(0), buf1);                                      // W1_1 + E_0
+        g2(0, buf1, W1(2), buf0);                                                     // W2_0
+        g1_with_e(a0, a1, 2, buf0, W2(1), buf1);                                      // W1_2 + E_1
+        g2(1, buf1, W1(3), buf0);                                                     // W2_1
+        g1_with_e(a1, a0, 3, buf0, W2(2), buf1);                                      // W1_3 + E_2
+        g2(2, buf1, W2(3), buf0);                                                     // W2_2
+        {                                                                             // E_3 on its own
+            const float *bias = vec + kVB1 + 3 * kC;
+            const float U = U1(3);
+            hid_load(S, bias, h, 0);
+#pragma unroll
+            for (int g = 0; g < 26; ++g) {
+                const f32x4 c0 = S.b0, c1 = S.b1;
+                hid_load(S, bias, h, g + 1);
+                hid_step(a1, U, hid, S, g, c0, c1);
+            }
+        }
+        g2(3, buf0, nullptr, buf1);                                                   // W2_3
+    } else {
 #pragma unroll 1
     for (int hb = 0; hb < 4; ++hb) {
         const float *w1 = mats + (size_t)(3 + 2 * hb) * kMatFloats;
@@ -197,6 +342,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
         gemm<WAVES>(acc_o, hid, buf0, msc + 2 * (4 + 2 * hb), lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
         skew_after_gemm(skew); PSTAMP(2)
+    }
     }
     layer_norm<true, false>(acc_o, vec + kVLqG, vec + kVLqB, h, eps);
     if constexpr (!kKeepRows) load_tile2(xr, out, row0, n_rows, xpose, lane);   // the wave's own earlier store
@@ -351,7 +497,9 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
     if (!agg || !s_proj || !x_res || !pack || !out) return QCN_ERR_INVALID_ARGUMENT;   // xn_dst may be NULL
     if (out == agg || out == xn_dst || out == s_proj || out == x_res) return QCN_ERR_INVALID_ARGUMENT;
     hipStream_t s = qcn_stream(stream);
-    const int waves = pick_waves(n_rows, 1.0);
+    // (split mode: the four-wave blocks run the feed-forward block software-pipelined — 0.90 of the eight-wave blocks' time
+    // per row at 960 k rows, same box)
+    const int waves = pick_waves(n_rows, matmul_mode == QCN_MATMUL_SPLIT_F16 ? 0.9 : 1.0);
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
     const int skew_mode = chain_skew_mode(0);
 #define QCN_LAUNCH(S, W)                                                                                          \

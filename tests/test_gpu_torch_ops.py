@@ -194,6 +194,33 @@ def test_op_gru_recurrence():
     assert rel_err(got, want) < 1e-5
 
 
+def test_op_trajectory_gru():
+    """FourierEmbedding -> GRU input matrices -> GRU recurrence as one op (modules/qcnet_decoder.py:255-257), against
+    torch.nn.GRU fed with the fp64 embedding."""
+    mode = ops.MATMUL_SPLIT_F16
+    torch.manual_seed(120)
+    m = FourierEmbedding(input_dim=2, hidden_dim=128, num_freq_bands=64).eval().to(DEV)
+    gru = torch.nn.GRU(128, 128).eval().to(DEV)
+    with torch.no_grad():
+        for prm in gru.parameters():
+            prm.copy_(torch.randn_like(prm) * 0.12)
+    n_seq, n_steps = 70, 9
+    x = _rand(n_seq * n_steps, 2, seed=121, scale=5.0).to(DEV)
+    h0 = (_rand(128, seed=122) * 0.3).to(DEV)
+    with torch.no_grad():
+        emb = m(continuous_inputs=x, categorical_embs=None)                       # [n_seq * n_steps, 128], row = seq * n_steps + t
+        want = gru.double()(emb.double().view(n_seq, n_steps, 128).transpose(0, 1).contiguous(),
+                            h0.double().view(1, 1, 128).repeat(1, n_seq, 1).contiguous())[1].squeeze(0)
+        gru.float()
+        w_ih = [w.contiguous() for w in gru.weight_ih_l0.chunk(3, dim=0)]
+        wt = ops.pack_chain_matrices(w_ih, mode=mode)
+        bias = gru.bias_ih_l0.view(3, 128).contiguous()
+        whh = ops.pack_gru_whh(gru.weight_hh_l0.detach(), h0, mode=mode)
+        got = op('trajectory_gru')(x, 2, n_steps, m.packed_weights(), wt, bias, False, whh, gru.bias_hh_l0.detach(), h0, mode)
+    assert got.shape == (n_seq, 128)
+    assert rel_err(got, want) < 2e-5
+
+
 def _pos_case(rep, seed):
     n_rows, n_src, E = 50, 60, 1500
     ei = _graph(n_src, n_rows, E, seed)
