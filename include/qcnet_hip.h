@@ -317,6 +317,26 @@ size_t qcn_attn_post_pack_floats(void);
 int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj, const float *x_res,
                       const float *pack, int64_t n_rows, float *out, int matmul_mode, void *stream);
 
+/* The same block for CHAINED layers (a stack of AttentionLayer calls in which one layer's output is the next one's
+ * destination input: modules/qcnet_decoder.py:219-227,259-263, qcnet_agent_encoder.py:181-187, qcnet_map_encoder.py:170-172).
+ * Two projections move into this kernel, where their input row already sits in registers:
+ *   - s_proj = to_s(attn_prenorm_x_dst(x_res)) (layers/attention_layer.py:108) is computed from the LayerNorm output the
+ *     gate needs anyway — it is neither written by qcn_ln_linear_f32 nor read back here;
+ *   - n_next > 0: y_j = W_j LN_next(out) + b_j, j < n_next <= 3 — the NEXT layer's attn_prenorm_x_dst + to_q (n_next = 1),
+ *     or attn_prenorm_x_src + to_q / to_k / to_v of a layer over one node set (n_next = 3), layers/attention_layer.py:74-79 of
+ *     the following call — applied to the output row before it leaves the registers: that layer then needs no
+ *     qcn_ln_linear_f32 launch for its destination rows.  next_wt / next_bias: the qcn_ln_linear_f32 layout (n_next
+ *     chain-packed matrices + their scale pairs; [n_next,128] or NULL); next_ln_weight / next_ln_bias: [128].
+ * pack (qcn_attn_post_chain_pack_floats() floats): 12 chain-packed matrices [to_g.weight[:, :128], to_g.weight[:, 128:],
+ *   to_s.weight, to_out.weight, then the eight feed-forward blocks as above], the vectors of qcn_attn_post_f32's pack,
+ *   to_s.bias, the scale table (32 floats).  Same arithmetic per element as qcn_ln_linear_f32 + qcn_attn_post_f32.
+ *   out and y_j must not alias an input or each other.  Runs in blocks of at most four waves (one wave per SIMD). */
+size_t qcn_attn_post_chain_pack_floats(void);
+int qcn_attn_post_chain_f32(const float *agg, const float *x_res, const float *pack, int64_t n_rows, float *out,
+                            const float *next_wt, const float *next_bias, const float *next_ln_weight,
+                            const float *next_ln_bias, int n_next, float *y0, float *y1, float *y2, int matmul_mode,
+                            void *stream);
+
 /* G0 / K7 — relative geometry of an edge list (utils/geometry.py:19-23 angle_between_2d_vectors, :47-51 wrap_angle, and
  * their call sites modules/qcnet_map_encoder.py:121-128, qcnet_agent_encoder.py:133-139,161-176, qcnet_decoder.py:161-206):
  *   dp = pos_src[src[e]] - pos_dst[dst[e]];  out[e] = [|dp|, angle(heading_dst, dp), wrap(head_src - head_dst) (, extra[e])]

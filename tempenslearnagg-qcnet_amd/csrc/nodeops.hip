@@ -77,6 +77,20 @@ constexpr int kVBg = 0, kVBout = kC, kVLpG = 2 * kC, kVLpB = 3 * kC, kVLfG = 4 *
               kVB2 = 10 * kC, kVLqG = 11 * kC, kVLqB = 12 * kC, kVPreG = 13 * kC, kVPreB = 14 * kC,
               kPostVecs = 15 * kC, kPostScales = 32;
 
+// Chained form (qcn_attn_post_chain_f32): to_s is computed here from the LN(x_dst) the gate needs anyway (the s projection
+// never goes through HBM), and the projections the NEXT layer applies to this layer's output (its LayerNorm + to_q, or
+// to_q / to_k / to_v) are applied to the output row while it is still in registers.
+// pack: 12 matrices [Wg_agg, Wg_x, Ws, Wout, W1_0, W2_0, ...], the vectors above, then bs, then the scale table.
+constexpr int kChainMats = 12, kVBs = kPostVecs, kChainVecs = kPostVecs + kC, kNextVecs = 5 * kC;   // next: ln_g, ln_b, 3 biases
+
+struct PostNext {
+    const float *wt;        // n chain-packed matrices + their {scale, 1 / scale} pairs (the qcn_ln_linear_f32 layout)
+    const float *bias;      // [n, 128] or nullptr
+    const float *ln_g, *ln_b;
+    float *y[3];
+    int n;                  // 0: no next-layer projections
+};
+
 #ifdef QCN_CHAIN_STAMPS
 // diagnostic build only (scripts/dbg/build_variant.sh stamps -DQCN_CHAIN_STAMPS): cycles of block 0 / waves 0 and 4 per
 // phase class {epilogue + loads, barrier wait, GEMM}, read back and printed by the entry point
@@ -183,15 +197,19 @@ __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[4], const Operand<kMode
     }
 }
 
-template <int MODE, int WAVES>
+template <int MODE, int WAVES, bool CHAIN = false>
 __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__restrict__ agg,
                                                                const float *__restrict__ xn,
                                                                const float *__restrict__ s,
                                                                const float *__restrict__ xres,
                                                                const float *__restrict__ pack, int64_t n_rows,
-                                                               float *__restrict__ out, int skew_mode)
+                                                               float *__restrict__ out, int skew_mode, PostNext next)
 {
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + (kPostVecs + kPostScales) / 4 + WAVES * 128];
+    static_assert(!CHAIN || WAVES <= 4, "the chained form holds the s projection in registers: one wave per SIMD");
+    constexpr int kVecFloats = (CHAIN ? kChainVecs : kPostVecs) + kPostScales + (CHAIN ? kNextVecs : 0);
+    constexpr int kMats = CHAIN ? kChainMats : kPostMats;
+    constexpr int kM = CHAIN ? 1 : 0;            // matrices behind Wg_x move up by one (Ws)
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + kVecFloats / 4 + WAVES * 128];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
     // (the vectors sit behind the two matrix buffers in ONE __shared__ array: with an array of their own hipcc's LDS-DMA
     // alias tracking put a vmcnt(0) in front of every LDS read, the weight fragments of the GEMM loop included)
@@ -199,19 +217,29 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t row0 = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave;
-    f32x4 *const xpose = wlds + 2 * kMatVec4 + (kPostVecs + kPostScales) / 4 + wave * 128;   // load_tile2 / store_tile2
+    f32x4 *const xpose = wlds + 2 * kMatVec4 + kVecFloats / 4 + wave * 128;   // load_tile2 / store_tile2
     const float *mats = pack;
     const float *vec = svec;
-    const float *msc = vec + kPostVecs;
+    const float *msc = vec + (CHAIN ? kChainVecs : kPostVecs);
+    const float *nvec = msc + kPostScales;     // CHAIN: ln_g, ln_b, biases of the next layer's projections
     const float eps = 1e-5f;
     Operand<MODE> op;
+    // the matrices alternate between the two buffers; behind Ws the parity flips
+    f32x4 *const bA = CHAIN ? wlds : wlds + kMatVec4, *const bB = CHAIN ? wlds + kMatVec4 : wlds;
 
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
 #ifdef QCN_CHAIN_STAMPS
     unsigned long long acc_t[4] = {0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
     stage_matrix<WAVES, MODE>(mats, buf0, wave, lane);
-    stage_vectors<WAVES>(pack + (size_t)kPostMats * kMatFloats, svec, kPostVecs + kPostScales, tid);
+    stage_vectors<WAVES>(pack + (size_t)kMats * kMatFloats, svec, (CHAIN ? kChainVecs : kPostVecs) + kPostScales, tid);
+    if constexpr (CHAIN) {
+        if (next.n > 0) {
+            float *nv = svec + kChainVecs + kPostScales;
+            for (int i = tid; i < kC; i += 64 * WAVES) { nv[i] = next.ln_g[i]; nv[kC + i] = next.ln_b[i]; }
+            for (int i = tid; i < next.n * kC; i += 64 * WAVES) nv[2 * kC + i] = next.bias != nullptr ? next.bias[i] : 0.f;
+        }
+    }
     __syncthreads();
     skew_begin(skew);
     // ---- gate: g = sigmoid(Wg [agg, xn] + bg)
@@ -247,7 +275,13 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     // ---- u = agg + g * (s - agg)
     {
         f32x16 vs[4];
-        load_tile2(vs, s, row0, n_rows, xpose, lane);
+        if constexpr (CHAIN) {   // s = Ws LN(x_dst) + bs: the gate's operand again (reference :108)
+            PSTAMP(0) sync_for_stage(); PSTAMP(1)
+            gemm_add<WAVES, MODE>(vs, op, buf0, msc + 4, lane, BiasTerm{vec + kVBs, h}, mats + 3 * kMatFloats, buf1, wave);
+            PSTAMP(2)
+        } else {
+            load_tile2(vs, s, row0, n_rows, xpose, lane);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -264,7 +298,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     // ---- x1 = x + LN_post(Wout u + bout)
     make_operand(op, va);
     PSTAMP(0) sync_for_stage(); PSTAMP(1)
-    gemm_add<WAVES, MODE>(acc, op, buf0, msc + 4, lane, BiasTerm{vec + kVBout, h}, mats + 3 * kMatFloats, buf1, wave);
+    gemm_add<WAVES, MODE>(acc, op, bB, msc + 2 * (2 + kM), lane, BiasTerm{vec + kVBout, h}, mats + (size_t)(3 + kM) * kMatFloats, bA, wave);
     skew_after_gemm(skew); PSTAMP(2)
     layer_norm<true, false>(acc, vec + kVLpG, vec + kVLpB, h, eps);
     if (!kKeepRows || xn != nullptr) load_tile2(xr, xres, row0, n_rows, xpose, lane);
@@ -280,9 +314,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     load_feature_vec(acc_o, vec + kVB2, h);
     constexpr bool kPipelined = MODE == kModeSplit && WAVES <= 4;
     if constexpr (kPipelined) {
-        auto W1 = [&](int hb) { return mats + (size_t)(3 + 2 * hb) * kMatFloats; };
-        auto W2 = [&](int hb) { return mats + (size_t)(4 + 2 * hb) * kMatFloats; };
-        auto U1 = [&](int hb) { return op.usc * msc[2 * (3 + 2 * hb) + 1]; };
+        auto W1 = [&](int hb) { return mats + (size_t)(3 + kM + 2 * hb) * kMatFloats; };
+        auto W2 = [&](int hb) { return mats + (size_t)(4 + kM + 2 * hb) * kMatFloats; };
+        auto U1 = [&](int hb) { return op.usc * msc[2 * (3 + kM + 2 * hb) + 1]; };
+        const float *after = CHAIN && next.n > 0 ? next.wt : nullptr;
         f32x16 a0[4], a1[4];
         Operand<MODE> hid;
         HidSteps S;
@@ -300,19 +335,19 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         };
         auto g2 = [&](int hb, f32x4 *wb, const float *nx, f32x4 *nb) {
             PSTAMP(0) sync_for_stage(); PSTAMP(1)
-            gemm<WAVES>(acc_o, hid, wb, msc + 2 * (4 + 2 * hb), lane, nx, nb, wave);
+            gemm<WAVES>(acc_o, hid, wb, msc + 2 * (4 + kM + 2 * hb), lane, nx, nb, wave);
             PSTAMP(2)
         };
         fill_zero(a0);
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
-        gemm_raw<WAVES, MODE>(a0, op, buf1, lane, W1(1), buf0, wave);                 // W1_0
+        gemm_raw<WAVES, MODE>(a0, op, bA, lane, W1(1), bB, wave);                     // W1_0
         PSTAMP(2)
-        g1_with_e(a1, a0, 1, buf0, W2(0), buf1);                                      // W1_1 + E_0
-        g2(0, buf1, W1(2), buf0);                                                     // W2_0
-        g1_with_e(a0, a1, 2, buf0, W2(1), buf1);                                      // W1_2 + E_1
-        g2(1, buf1, W1(3), buf0);                                                     // W2_1
-        g1_with_e(a1, a0, 3, buf0, W2(2), buf1);                                      // W1_3 + E_2
-        g2(2, buf1, W2(3), buf0);                                                     // W2_2
+        g1_with_e(a1, a0, 1, bB, W2(0), bA);                                          // W1_1 + E_0
+        g2(0, bA, W1(2), bB);                                                         // W2_0
+        g1_with_e(a0, a1, 2, bB, W2(1), bA);                                          // W1_2 + E_1
+        g2(1, bA, W1(3), bB);                                                         // W2_1
+        g1_with_e(a1, a0, 3, bB, W2(2), bA);                                          // W1_3 + E_2
+        g2(2, bA, W2(3), bB);                                                         // W2_2
         {                                                                             // E_3 on its own
             const float *bias = vec + kVB1 + 3 * kC;
             const float U = U1(3);
@@ -324,14 +359,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
                 hid_step(a1, U, hid, S, g, c0, c1);
             }
         }
-        g2(3, buf0, nullptr, buf1);                                                   // W2_3
+        g2(3, bB, after, bA);                                                         // W2_3
     } else {
+    const float *after = CHAIN && next.n > 0 ? next.wt : nullptr;
 #pragma unroll 1
     for (int hb = 0; hb < 4; ++hb) {
-        const float *w1 = mats + (size_t)(3 + 2 * hb) * kMatFloats;
+        const float *w1 = mats + (size_t)(3 + kM + 2 * hb) * kMatFloats;
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
-        gemm_add<WAVES, MODE>(acc, op, buf1, msc + 2 * (3 + 2 * hb), lane, BiasTerm{vec + kVB1 + hb * kC, h}, w1 + kMatFloats,
-                              buf0, wave);
+        gemm_add<WAVES, MODE>(acc, op, bA, msc + 2 * (3 + kM + 2 * hb), lane, BiasTerm{vec + kVB1 + hb * kC, h}, w1 + kMatFloats,
+                              bB, wave);
         skew_after_gemm(skew); PSTAMP(2)
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -340,7 +376,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         Operand<MODE> hid;
         make_operand(hid, acc);
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
-        gemm<WAVES>(acc_o, hid, buf0, msc + 2 * (4 + 2 * hb), lane, hb < 3 ? w1 + 2 * kMatFloats : nullptr, buf1, wave);
+        gemm<WAVES>(acc_o, hid, bB, msc + 2 * (4 + kM + 2 * hb), lane, hb < 3 ? w1 + 2 * kMatFloats : after, bA, wave);
         skew_after_gemm(skew); PSTAMP(2)
     }
     }
@@ -349,6 +385,22 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc_o[t] += xr[t];
     store_tile2(acc_o, out, row0, n_rows, xpose, lane);
+    if constexpr (CHAIN) {
+        // ---- the next layer's LayerNorm + projections of this row (its attn_prenorm_x_dst + to_q, or x_src + to_q / to_k / to_v
+        // for a layer over one node set): qcn_ln_linear_f32's arithmetic on the row it would have read back
+        if (next.n > 0) {
+            layer_norm<true, false>(acc_o, nvec, nvec + kC, h, eps);
+            make_operand(op, acc_o);
+            const float *nsc = next.wt + (size_t)next.n * kMatFloats;
+#pragma unroll 1
+            for (int j = 0; j < next.n; ++j) {
+                sync_for_stage();
+                gemm_add<WAVES, MODE>(acc, op, (j & 1) ? bB : bA, nsc + 2 * j, lane, BiasTerm{nvec + (2 + j) * kC, h},
+                                      j + 1 < next.n ? next.wt + (size_t)(j + 1) * kMatFloats : nullptr, (j & 1) ? bA : bB, wave);
+                store_tile2(acc, next.y[j], row0, n_rows, xpose, lane);
+            }
+        }
+    }
     skew_end(skew);
 #ifdef QCN_CHAIN_STAMPS
     PSTAMP(0)
@@ -469,6 +521,42 @@ extern "C" int qcn_mlp_heads_f32(const float *x, int64_t n_rows, const float *pa
 
 extern "C" size_t qcn_attn_post_pack_floats(void) { return (size_t)kPostMats * kMatFloats + kPostVecs + kPostScales; }
 
+extern "C" size_t qcn_attn_post_chain_pack_floats(void) { return (size_t)kChainMats * kMatFloats + kChainVecs + kPostScales; }
+
+extern "C" int qcn_attn_post_chain_f32(const float *agg, const float *x_res, const float *pack, int64_t n_rows, float *out,
+                                       const float *next_wt, const float *next_bias, const float *next_ln_weight,
+                                       const float *next_ln_bias, int n_next, float *y0, float *y1, float *y2, int matmul_mode,
+                                       void *stream)
+{
+    if (n_rows < 0 || n_next < 0 || n_next > 3 || !valid_mode(matmul_mode)) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_rows == 0) return QCN_OK;
+    if (!agg || !x_res || !pack || !out || out == agg || out == x_res) return QCN_ERR_INVALID_ARGUMENT;
+    if (n_next > 0 && (!next_wt || !next_ln_weight || !next_ln_bias || !y0 || (n_next > 1 && !y1) || (n_next > 2 && !y2)))
+        return QCN_ERR_INVALID_ARGUMENT;
+    for (float *y : {y0, y1, y2})
+        if (y != nullptr && n_next > 0 && (y == out || y == agg || y == x_res)) return QCN_ERR_INVALID_ARGUMENT;
+    hipStream_t s = qcn_stream(stream);
+    // one wave per SIMD: the s projection stays in registers beside the gate's accumulators (eight-wave blocks have 256)
+    int waves = pick_waves(n_rows, 0.9);
+    if (waves > 4) waves = 4;
+    const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
+    const PostNext next{next_wt, next_bias, next_ln_weight, next_ln_bias, {y0, y1, y2}, n_next};
+#define QCN_LAUNCH_C(M)                                                                                                     \
+    do {                                                                                                                    \
+        if (waves == 4)                                                                                                     \
+            hipLaunchKernelGGL((attn_post_kernel<M, 4, true>), dim3(grid), dim3(256), 0, s, agg, nullptr, nullptr, x_res, pack, \
+                               n_rows, out, 0, next);                                                                       \
+        else                                                                                                                \
+            hipLaunchKernelGGL((attn_post_kernel<M, 2, true>), dim3(grid), dim3(128), 0, s, agg, nullptr, nullptr, x_res, pack, \
+                               n_rows, out, 0, next);                                                                       \
+    } while (0)
+    if (matmul_mode == QCN_MATMUL_SPLIT_F16) QCN_LAUNCH_C(QCN_MATMUL_SPLIT_F16);
+    else if (matmul_mode == QCN_MATMUL_BF16) QCN_LAUNCH_C(QCN_MATMUL_BF16);
+    else QCN_LAUNCH_C(QCN_MATMUL_EXACT_F32);
+#undef QCN_LAUNCH_C
+    return hipGetLastError() == hipSuccess ? QCN_OK : QCN_ERR_LAUNCH_FAILED;
+}
+
 extern "C" int qcn_ln_linear_f32(const float *x, int64_t n_rows, const float *ln_weight, const float *ln_bias,
                                  const float *wt, const float *bias, int n_out, float *y0, float *y1, float *y2,
                                  float *y3, float *xn_out, int matmul_mode, void *stream)
@@ -504,7 +592,7 @@ extern "C" int qcn_attn_post_f32(const float *agg, const float *xn_dst, const fl
     const int skew_mode = chain_skew_mode(0);
 #define QCN_LAUNCH(S, W)                                                                                          \
     hipLaunchKernelGGL((attn_post_kernel<S, W>), dim3(grid), dim3(64 * W), 0, s, agg, xn_dst, s_proj, x_res, pack, n_rows, \
-                       out, skew_mode)
+                       out, skew_mode, PostNext{})
     QCN_CHAIN_DISPATCH(matmul_mode, waves);
 #undef QCN_LAUNCH
     const bool ok = hipGetLastError() == hipSuccess;

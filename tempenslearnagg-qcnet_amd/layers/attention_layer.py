@@ -42,6 +42,11 @@ def _tables_fit(graph, device) -> bool:
 
 CACHE_EDGE_PROJECTIONS = os.environ.get('QCN_EDGE_KV_CACHE', '1') != '0'
 
+# node side of a layer as ONE launch behind the propagate (qcn_attn_post_chain_f32: to_s computed in the kernel, the next
+# layer's destination-side projections applied to the output row); QCN_ATTN_CHAIN=0: qcn_ln_linear_f32 writes s, the next
+# layer projects its own destination rows (A/B runs)
+CHAIN_NODE_SIDE = os.environ.get('QCN_ATTN_CHAIN', '1') != '0'
+
 
 class NormalizedEdgeFeatures:
     """Positional embeddings of a relation after the layer-independent half of ``attn_prenorm_r``:
@@ -186,17 +191,23 @@ class AttentionLayer(nn.Module):
                                 torch.stack([self.to_q.bias, self.to_s.bias]).contiguous())
             packs['pre_all'] = (stack(self.to_q, self.to_k, self.to_v, self.to_s),
                                 torch.stack([self.to_q.bias, zero, self.to_v.bias, self.to_s.bias]).contiguous())
-            mats = [self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_out.weight]
+            # chained node side (qcn_attn_post_chain_f32 computes s): what is left for qcn_ln_linear_f32 / the previous layer
+            packs['pre_q'] = (stack(self.to_q), self.to_q.bias.reshape(1, C).contiguous())
+            packs['pre_qkv'] = (stack(self.to_q, self.to_k, self.to_v),
+                                torch.stack([self.to_q.bias, zero, self.to_v.bias]).contiguous())
             w1, w2 = self.ff_mlp[0], self.ff_mlp[3]
+            ffn = []
             for hb in range(4):
-                mats += [w1.weight[hb * C:(hb + 1) * C, :], w2.weight[:, hb * C:(hb + 1) * C]]
-            mats, scales = ops.pack_chain_set(mats, mode=mode)
-            mats = [mats]
+                ffn += [w1.weight[hb * C:(hb + 1) * C, :], w2.weight[:, hb * C:(hb + 1) * C]]
             vecs = [self.to_g.bias, self.to_out.bias, self.attn_postnorm.weight, self.attn_postnorm.bias,
                     self.ff_prenorm.weight, self.ff_prenorm.bias, w1.bias, w2.bias, self.ff_postnorm.weight,
                     self.ff_postnorm.bias, self.attn_prenorm_x_dst.weight, self.attn_prenorm_x_dst.bias]
-            packs['post'] = torch.cat([m.reshape(-1) for m in mats] + [v.reshape(-1).float() for v in vecs]
-                                      + [ops.scale_table(scales)]).contiguous()
+            for name, head, tail in (('post', [self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_out.weight], []),
+                                     ('post_chain', [self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_s.weight,
+                                                     self.to_out.weight], [self.to_s.bias])):
+                mats, scales = ops.pack_chain_set(head + ffn, mode=mode)
+                packs[name] = torch.cat([mats.reshape(-1)] + [v.reshape(-1).float() for v in vecs + tail]
+                                        + [ops.scale_table(scales)]).contiguous()
             if self.has_pos_emb:
                 gamma, beta = self.attn_prenorm_r.weight, self.attn_prenorm_r.bias
                 packs['pos'] = ((self.to_k_r.weight * gamma.unsqueeze(0)).contiguous(),
@@ -210,14 +221,21 @@ class AttentionLayer(nn.Module):
                 x: Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]],
                 r: Union[None, torch.Tensor, NormalizedEdgeFeatures],
                 edge_index: Union[torch.Tensor, CSRGraph],
-                source_cache: Optional[dict] = None) -> torch.Tensor:
+                source_cache: Optional[dict] = None,
+                pre: Optional[Tuple[torch.Tensor, ...]] = None,
+                next_layer: Optional['AttentionLayer'] = None):
         """``r``: the relation's positional embedding, one row per edge of ``edge_index`` in its order (for a
         mode-replicated CSRGraph: one row per *base* edge), either raw (reference semantics) or already
         row-normalised (``NormalizedEdgeFeatures``).
         ``source_cache`` (bipartite calls only; not in the reference): a dict owned by the caller in which the layer keeps
         the key / value projections of ``x[0]``.  A caller that applies this layer several times to the SAME source rows
         (the decoder's recurrent proposal steps, modules/qcnet_decoder.py:219-227) passes the same dict and the projections
-        are computed once; the caller guarantees ``x[0]`` and the layer's weights do not change while it holds the dict."""
+        are computed once; the caller guarantees ``x[0]`` and the layer's weights do not change while it holds the dict.
+        ``next_layer`` / ``pre`` (not in the reference) chain a stack of layers in which this layer's output is the next
+        one's destination input (x[1], or x of a layer over one node set): with ``next_layer`` the call returns
+        ``(out, pre_next)`` where ``pre_next`` holds that layer's LayerNorm + to_q (bipartite) or to_q / to_k / to_v projections
+        of ``out``, computed while the row was in registers; the caller hands it to that layer as ``pre`` (together with
+        the very tensor ``out`` as its destination input) and the layer launches no projection of its destination rows."""
         if self.training and self.dropout > 0:
             raise RuntimeError('AttentionLayer is inference-only: call .eval() (dropout is not implemented)')
         packs = self._kernel_packs()
@@ -257,10 +275,24 @@ class AttentionLayer(nn.Module):
             else:
                 kv = kept_kv[1]
             k, v = kv
-            (q, s), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'], mode=mode)
+            if pre is not None:
+                (q,), s = pre, None
+            elif CHAIN_NODE_SIDE:
+                (q,), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_q'], mode=mode)
+                s = None
+            else:
+                (q, s), _ = ops.ln_linear(x_res, ln_d.weight, ln_d.bias, *packs['pre_dst'], mode=mode)
         else:
             ln = self.attn_prenorm_x_src
-            (q, k, v, s), _ = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_all'], mode=mode)
+            if pre is not None:
+                (q, k, v), s = pre, None
+            elif CHAIN_NODE_SIDE:
+                (q, k, v), _ = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_qkv'], mode=mode)
+                s = None
+            else:
+                (q, k, v, s), _ = ops.ln_linear(x_res, ln.weight, ln.bias, *packs['pre_all'], mode=mode)
+        if q.size(0) != n_dst:
+            raise ValueError('pre holds %d destination rows, x has %d' % (q.size(0), n_dst))
         # propagate: gather + segment softmax + weighted scatter-add (one launch)
         if r is not None:
             wk, wv, bv = packs['pos']
@@ -302,7 +334,28 @@ class AttentionLayer(nn.Module):
             agg = ops.attn_fwd(q, k, v, None, None, graph.rowptr, graph.col, graph.eid)
         # post: gate/update, to_out, post-norm residual, feed-forward block (one launch)
         # the gate's LN(x_dst) is recomputed inside the kernel (xn_dst = None): cheaper than a [N, 128] round trip
-        return ops.attn_post(agg, None, s, x_res, packs['post'], mode=mode)
+        if s is not None:
+            out = ops.attn_post(agg, None, s, x_res, packs['post'], mode=mode)
+            return out if next_layer is None else (out, next_layer.project_destinations(out))
+        if next_layer is None:
+            return ops.attn_post_chain(agg, x_res, packs['post_chain'], mode=mode)[0]
+        nwt, nbias, nln = next_layer._destination_projection()
+        outs = ops.attn_post_chain(agg, x_res, packs['post_chain'], nwt, nbias, nln.weight, nln.bias, mode=mode)
+        return outs[0], tuple(outs[1:])
+
+    def _destination_projection(self):
+        """(weights, biases, LayerNorm) of what this layer applies to its destination rows before the propagate: to_q behind
+        attn_prenorm_x_dst (bipartite), to_q / to_k / to_v behind the shared LayerNorm (one node set)."""
+        packs = self._kernel_packs()
+        if self.bipartite:
+            return packs['pre_q'] + (self.attn_prenorm_x_dst,)
+        return packs['pre_qkv'] + (self.attn_prenorm_x_src,)
+
+    def project_destinations(self, x_dst: torch.Tensor) -> Tuple[torch.Tensor, ...]:
+        """``pre`` of :meth:`forward` for destination rows ``x_dst`` as a launch of its own (the unchained form)."""
+        wt, bias, ln = self._destination_projection()
+        ys, _ = ops.ln_linear(x_dst.contiguous(), ln.weight, ln.bias, wt, bias, mode=self._kernel_packs()['mode'])
+        return tuple(ys)
 
     @staticmethod
     def edge_table_bytes(graph: CSRGraph) -> int:

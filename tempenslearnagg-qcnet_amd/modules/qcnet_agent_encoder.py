@@ -13,6 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..layers import attention_layer
 from ..layers import AttentionLayer, FourierEmbedding, NormalizedEdgeFeatures
 from ..utils.geometry import angle_between_2d_vectors
 from ..utils.graph import CSRGraph, mask_outer_edges
@@ -122,10 +123,17 @@ class QCNetAgentEncoder(nn.Module):
             x_a = x_a.reshape(-1, C)
             x_a = self.t_attn_layers[i](x_a, r_t, g_t)
             x_a = x_a.reshape(-1, T, C).transpose(0, 1).reshape(-1, C)
-            x_a = self.pl2a_attn_layers[i]((x_pl, x_a), r_pl2a, g_pl2a)
-            x_a = self.a2a_attn_layers[i](x_a, r_a2a, g_a2a)
+            x_a = self._pl2a_a2a(i, x_pl, x_a, r_pl2a, g_pl2a, r_a2a, g_a2a)
             x_a = x_a.reshape(T, -1, C).transpose(0, 1)
         return x_a
+
+    def _pl2a_a2a(self, i: int, x_pl, x_a, r_pl2a, g_pl2a, r_a2a, g_a2a, pre=None) -> torch.Tensor:
+        """Layer i's polygon->agent and agent->agent attention over the same (time-major) rows, chained: the first one's
+        node-side kernel also applies the second one's LayerNorm + to_q / to_k / to_v (layers/attention_layer.py)."""
+        if not attention_layer.CHAIN_NODE_SIDE:
+            return self.a2a_attn_layers[i](self.pl2a_attn_layers[i]((x_pl, x_a), r_pl2a, g_pl2a), r_a2a, g_a2a)
+        x_a, qkv = self.pl2a_attn_layers[i]((x_pl, x_a), r_pl2a, g_pl2a, pre=pre, next_layer=self.a2a_attn_layers[i])
+        return self.a2a_attn_layers[i](x_a, r_a2a, g_a2a, pre=qkv)
 
     # ------------------------------------------------------------------------------------------------------------
     # sliding-window reuse: everything that depends on ABSOLUTE time only, computed once for all frames
@@ -233,8 +241,7 @@ class QCNetAgentEncoder(nn.Module):
             x_a = x_a.reshape(-1, C)                                                     # (f, a, t)
             x_a = self.t_attn_layers[i](x_a, cache['r_t'], g_t)
             x_a = x_a.view(F, A, T, C).transpose(1, 2).reshape(-1, C)                    # (f, t, a)
-            x_a = self.pl2a_attn_layers[i]((x_pl, x_a), cache['r_pl2a'], g_pl2a)
-            x_a = self.a2a_attn_layers[i](x_a, cache['r_a2a'], g_a2a)
+            x_a = self._pl2a_a2a(i, x_pl, x_a, cache['r_pl2a'], g_pl2a, cache['r_a2a'], g_a2a)
             x_a = x_a.view(F, T, A, C).transpose(1, 2)                                   # (f, a, t)
         return x_a.reshape(F * A, T, C)
 
@@ -284,10 +291,14 @@ class QCNetAgentEncoder(nn.Module):
             # input rows: [long run | the special destinations' own rows | special rows of the previous layer]; the
             # first NA + n_own output rows are the ones that go on
             inp = torch.cat([z[:NA], z[L['own_idx']], z[NA:]]) if L['n_own'] else z[:NA]
-            y = self.t_attn_layers[l - 1](inp, cache['r_t'], L['g_t'])
-            x2 = y[:NA + L['n_own']]
-            z = self.pl2a_attn_layers[l - 1]((x_pl, x2), cache['r_pl2a'], L['g_pl2a'])
-            z = self.a2a_attn_layers[l - 1](z, cache['r_a2a'], L['g_a2a'])
+            # (the rows that go on are a prefix of the temporal layer's output: so are their chained projections)
+            n_on = NA + L['n_own']
+            if attention_layer.CHAIN_NODE_SIDE:
+                y, (q,) = self.t_attn_layers[l - 1](inp, cache['r_t'], L['g_t'], next_layer=self.pl2a_attn_layers[l - 1])
+                pre = (q[:n_on],)
+            else:
+                y, pre = self.t_attn_layers[l - 1](inp, cache['r_t'], L['g_t']), None
+            z = self._pl2a_a2a(l - 1, x_pl, y[:n_on], cache['r_pl2a'], L['g_pl2a'], cache['r_a2a'], L['g_a2a'], pre=pre)
         return z, plan['index']          # the last layer's output already is [long run | special rows]
 
     def _stream_plan_graphs(self, cache, A: int, P: int, needed_from: int):

@@ -151,11 +151,18 @@ class QCNetDecoder(nn.Module):
         # (:223,226).  The kernel takes the node order of a mode-replicated relation as a parameter, so m stays
         # agent-major throughout and the four transposes per layer pair disappear.
         m = m.reshape(-1, C)
+        # every layer's output is the next layer's destination input and nothing else: the stack runs chained (each layer's
+        # node-side kernel also applies the next layer's destination-side LayerNorm + projections, layers/attention_layer.py)
+        stack = []
         for i in range(self.num_layers):
-            m = t2m[i]((x_t, m), r_t2m, g_t2m, source_cache)
-            m = pl2m[i]((x_pl, m), r_pl2m, g_pl2m, source_cache)
-            m = a2m[i]((x_a, m), r_a2m, g_a2m, source_cache)
-        m = getattr(self, 'm2m_%s_attn_layer' % stage)(m, None, g_m2m)
+            stack += [(t2m[i], x_t, r_t2m, g_t2m), (pl2m[i], x_pl, r_pl2m, g_pl2m), (a2m[i], x_a, r_a2m, g_a2m)]
+        stack.append((getattr(self, 'm2m_%s_attn_layer' % stage), None, None, g_m2m))
+        pre = None
+        for j, (layer, x_src, r, g) in enumerate(stack):
+            nxt = stack[j + 1][0] if j + 1 < len(stack) and attention_layer.CHAIN_NODE_SIDE else None
+            res = layer(m if x_src is None else (x_src, m), r, g, source_cache if x_src is not None else None,
+                        pre=pre, next_layer=nxt)
+            m, pre = res if nxt is not None else (res, None)
         return m.reshape(-1, K, C)
 
     def _decode(self, data, scene_enc: Mapping[str, torch.Tensor], time_shift: int,

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..layers import attention_layer
 from ..layers import AttentionLayer, FourierEmbedding, NormalizedEdgeFeatures
 from ..utils.graph import CSRGraph, merge_edges
 from ..utils.weight_init import weight_init
@@ -114,8 +115,14 @@ class QCNetMapEncoder(nn.Module):
 
         x_pt, x_pl, g_pt2pl, r_pt2pl, g_pl2pl, r_pl2pl, ei_pl2pl, type_pl2pl = run_prep(
             data['map_polygon']['position'].device, prepare)
+        # chained stack (layers/attention_layer.py: each layer's node-side kernel also projects the next layer's destinations)
+        stack = []
         for i in range(self.num_layers):
-            x_pl = self.pt2pl_layers[i]((x_pt, x_pl), r_pt2pl, g_pt2pl)
-            x_pl = self.pl2pl_layers[i](x_pl, r_pl2pl, g_pl2pl)
+            stack += [(self.pt2pl_layers[i], x_pt, r_pt2pl, g_pt2pl), (self.pl2pl_layers[i], None, r_pl2pl, g_pl2pl)]
+        pre = None
+        for j, (layer, x_src, r, g) in enumerate(stack):
+            nxt = stack[j + 1][0] if j + 1 < len(stack) and attention_layer.CHAIN_NODE_SIDE else None
+            res = layer(x_pl if x_src is None else (x_src, x_pl), r, g, pre=pre, next_layer=nxt)
+            x_pl, pre = res if nxt is not None else (res, None)
         x_pl = x_pl.unsqueeze(1).expand(-1, self.num_historical_steps, -1)
         return {'x_pt': x_pt, 'x_pl': x_pl, 'edge_index_pl2pl': ei_pl2pl, 'type_pl2pl': type_pl2pl}

@@ -645,6 +645,51 @@ def _attn_post(agg, xn_dst, s_proj, x_res, pack, mode):
     return out
 
 
+def attn_post_chain(agg: torch.Tensor, x_res: torch.Tensor, pack: torch.Tensor, next_wt: Optional[torch.Tensor] = None,
+                    next_bias: Optional[torch.Tensor] = None, next_ln_weight: Optional[torch.Tensor] = None,
+                    next_ln_bias: Optional[torch.Tensor] = None, mode: Optional[int] = None) -> List[torch.Tensor]:
+    """qcn_attn_post_chain_f32: ``[out, y_0 .. y_{n_next-1}]`` — the node-side block of one AttentionLayer with to_s computed
+    inside (``pack``: 12 matrices, see include/qcnet_hip.h) and, with ``next_wt``, the next layer's LayerNorm + projections
+    applied to the output row (``next_wt`` / ``next_bias`` as for :func:`ln_linear`, 1..3 matrices)."""
+    return list(_op('attn_post_chain')(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, _mode(mode)))
+
+
+def _attn_post_chain_fake(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, mode):
+    n_next = 0 if next_wt is None else next_wt.numel() // (C * C + 2)
+    return [torch.empty_like(agg) for _ in range(1 + n_next)]
+
+
+@_register('attn_post_chain', '(Tensor agg, Tensor x_res, Tensor pack, Tensor? next_wt, Tensor? next_bias, Tensor? next_ln_weight, '
+           'Tensor? next_ln_bias, int mode) -> Tensor[]', _attn_post_chain_fake)
+def _attn_post_chain(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, mode):
+    dev = agg.device
+    n = agg.size(0)
+    _require(agg, 'agg', torch.float32, dev, (n, C))
+    _require(x_res, 'x_res', torch.float32, dev, (n, C))
+    _require(pack, 'pack', torch.float32, dev, (_lib.lib().qcn_attn_post_chain_pack_floats(),))
+    n_next = 0
+    if next_wt is not None:
+        n_next = next_wt.numel() // (C * C + 2)
+        if not 1 <= n_next <= 3:
+            raise ValueError('next_wt must hold 1..3 matrices')
+        _require(next_wt, 'next_wt', torch.float32, dev, (n_next * (C * C + 2),))
+        if next_bias is not None:
+            _require(next_bias, 'next_bias', torch.float32, dev, (n_next, C))
+        if next_ln_weight is None or next_ln_bias is None:
+            raise ValueError('next_wt needs next_ln_weight and next_ln_bias')
+        _require(next_ln_weight, 'next_ln_weight', torch.float32, dev, (C,))
+        _require(next_ln_bias, 'next_ln_bias', torch.float32, dev, (C,))
+    outs = [torch.empty(n, C, dtype=torch.float32, device=dev) for _ in range(1 + n_next)]
+    yp = [_ptr(y) for y in outs[1:]] + [None] * (3 - n_next)
+    tok = _prof_begin(PROF_GEMM, float(n) * (12 + n_next) * 2.0 * C * C, dev)
+    _lib.check(_lib.lib().qcn_attn_post_chain_f32(_ptr(agg), _ptr(x_res), _ptr(pack), n, _ptr(outs[0]), _ptr(next_wt),
+                                                  _ptr(next_bias) if n_next else None, _ptr(next_ln_weight) if n_next else None,
+                                                  _ptr(next_ln_bias) if n_next else None, n_next, yp[0], yp[1], yp[2], int(mode),
+                                                  _stream(dev)), 'qcn_attn_post_chain_f32')
+    _prof_end(tok, dev)
+    return outs
+
+
 def rel_geometry(pos_src: torch.Tensor, pos_dst: torch.Tensor, head_src: torch.Tensor, head_dst: torch.Tensor,
                  edge_index: torch.Tensor, extra: Optional[torch.Tensor] = None) -> torch.Tensor:
     """qcn_rel_geometry_f32: [E, 3 (4 with ``extra``)] relative-geometry rows of an edge list ([2, E] int64, row 0 indexes

@@ -417,3 +417,44 @@ def test_trajectory_gru_blocked_layout_equals_row_major(n_seq, in_dim, folded, m
         got = ops.trajectory_gru(x, in_dim, n_steps, emb.packed_weights(), wt, bs, folded, whh, b_hh, h0, mode=mode)
     assert got.shape == (n_seq, 128) and bool(torch.isfinite(got).all())
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize('mode', [1, 0])
+def test_chained_layers_equal_unchained(mode, restore_matmul_mode):
+    """A stack bipartite -> one-node-set -> bipartite run chained (each layer's node-side kernel applies the next layer's
+    destination-side LayerNorm + projections and computes to_s itself: qcn_attn_post_chain_f32) against the same stack with
+    every layer projecting its own rows (qcn_ln_linear_f32 + qcn_attn_post_f32): the same arithmetic per element, up to
+    the order in which a bias joins its dot product (1e-5)."""
+    from tempenslearnagg_qcnet_amd.layers import AttentionLayer, attention_layer
+    ops.set_matmul_mode(mode)
+    torch.manual_seed(31)
+    n_src, n_dst, E = 90, 333, 4000
+    layers = [AttentionLayer(128, 8, 16, 0.0, bipartite=b, has_pos_emb=True).to(DEV).eval() for b in (True, False, True)]
+    with torch.no_grad():
+        for layer in layers:
+            for name, p in layer.named_parameters():
+                if p.dim() == 1:
+                    p.add_(torch.randn_like(p) * 0.1)
+    x_src, x = torch.randn(n_src, 128, device=DEV), torch.randn(n_dst, 128, device=DEV)
+    g = torch.Generator().manual_seed(5)
+    ei_b = torch.stack([torch.randint(0, n_src, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)]).to(DEV)
+    ei_s = torch.stack([torch.randint(0, n_dst, (E,), generator=g), torch.randint(0, n_dst, (E,), generator=g)]).to(DEV)
+    r_b, r_s = torch.randn(E, 128, device=DEV), torch.randn(E, 128, device=DEV)
+
+    def run(chain):
+        attention_layer.CHAIN_NODE_SIDE = chain
+        with torch.no_grad():
+            if not chain:
+                y = layers[0]((x_src, x), r_b, ei_b)
+                y = layers[1](y, r_s, ei_s)
+                return layers[2]((x_src, y), r_b, ei_b)
+            y, pre = layers[0]((x_src, x), r_b, ei_b, next_layer=layers[1])
+            assert len(pre) == 3
+            y, pre = layers[1](y, r_s, ei_s, pre=pre, next_layer=layers[2])
+            assert len(pre) == 1
+            return layers[2]((x_src, y), r_b, ei_b, pre=pre)
+    try:
+        want, got = run(False), run(True)
+    finally:
+        attention_layer.CHAIN_NODE_SIDE = True
+    assert rel_err(got, want) < 1e-5

@@ -115,6 +115,47 @@ def test_op_attn_post():
     assert rel_err(got, _torch_attn_post(agg, s, x, p)) < 1e-5
 
 
+@pytest.mark.parametrize('mode,n_next,n_rows', [(ops.MATMUL_SPLIT_F16, 0, 700), (ops.MATMUL_SPLIT_F16, 1, 700),
+                                               (ops.MATMUL_SPLIT_F16, 3, 77), (ops.MATMUL_EXACT_F32, 3, 300),
+                                               (ops.MATMUL_BF16, 1, 130)])
+def test_op_attn_post_chain(mode, n_next, n_rows):
+    """qcn_attn_post_chain_f32: to_s inside the kernel and the next layer's LayerNorm + projections on the output row, against
+    the fp64 torch form of layers/attention_layer.py:83-84,106-108,119-122 (+ :74-79 of the following call)."""
+    mk = lambda *s, seed, scale=0.1: _rand(*s, seed=seed, scale=scale).double()
+    p = dict(wg=mk(128, 256, seed=30), bg=mk(128, seed=31), wo=mk(128, 128, seed=32), bo=mk(128, seed=33),
+             w1=mk(512, 128, seed=34), b1=mk(512, seed=35), w2=mk(128, 512, seed=36), b2=mk(128, seed=37),
+             ws=mk(128, 128, seed=38), bs=mk(128, seed=39))
+    for i, n in enumerate(('lp', 'lf', 'lq', 'pre', 'nx')):
+        p[n + '_g'] = 1.0 + mk(128, seed=40 + i)
+        p[n + '_b'] = mk(128, seed=50 + i)
+    f = lambda t: t.float().to(DEV)
+    mats = [f(p['wg'][:, :128]), f(p['wg'][:, 128:]), f(p['ws']), f(p['wo'])]
+    for hb in range(4):
+        mats += [f(p['w1'][128 * hb:128 * hb + 128]), f(p['w2'][:, 128 * hb:128 * hb + 128])]
+    packed, scales = ops.pack_chain_set(mats, mode=mode)
+    vecs = [p['bg'], p['bo'], p['lp_g'], p['lp_b'], p['lf_g'], p['lf_b'], p['b1'], p['b2'], p['lq_g'], p['lq_b'], p['pre_g'],
+            p['pre_b'], p['bs']]
+    pack = torch.cat([packed.reshape(-1)] + [f(v).reshape(-1) for v in vecs] + [ops.scale_table(scales)]).contiguous()
+    agg, x = (_rand(n_rows, 128, seed=60 + i).double() for i in range(2))
+    nw = [mk(128, 128, seed=80 + j) for j in range(n_next)]
+    nb = mk(max(n_next, 1), 128, seed=90)[:n_next]
+    args = [None] * 4
+    if n_next:
+        args = [ops.pack_chain_matrices([f(w) for w in nw], mode=mode), f(nb), f(p['nx_g']), f(p['nx_b'])]
+    outs = op('attn_post_chain')(f(agg), f(x), pack, *args, mode)
+    assert len(outs) == 1 + n_next
+    if mode == ops.MATMUL_BF16:   # every matrix operand rounded to bf16: compare loosely with the fp64 form (exercises the path)
+        tol = 3e-2
+    else:
+        tol = 1e-5
+    s = F.linear(F.layer_norm(x, (128,), p['pre_g'], p['pre_b'], 1e-5), p['ws'], p['bs'])
+    want = _torch_attn_post(agg, s, x, p)
+    assert rel_err(outs[0], want) < tol
+    wn = F.layer_norm(outs[0].double().cpu() if mode == ops.MATMUL_BF16 else want, (128,), p['nx_g'], p['nx_b'], 1e-5)
+    for j in range(n_next):
+        assert rel_err(outs[1 + j], wn @ nw[j].t() + nb[j]) < (2e-2 if mode == ops.MATMUL_BF16 else 2e-5)
+
+
 def test_op_fourier_embed_and_fourier_linear():
     m = FourierEmbedding(input_dim=2, hidden_dim=128, num_freq_bands=64).eval().to(DEV)
     with torch.no_grad():
