@@ -337,6 +337,15 @@ int qcn_attn_post_chain_f32(const float *agg, const float *x_res, const float *p
                             const float *next_ln_bias, int n_next, float *y0, float *y1, float *y2, int matmul_mode,
                             void *stream);
 
+/* M4 glue — the cumulative way-points of the decoder's recurrent proposal steps (modules/qcnet_decoder.py:234-250): chunk c
+ * (c < n_chunks <= 4, host array of device pointers) holds the increments of steps [c * steps_per_chunk, (c + 1) *
+ * steps_per_chunk) as [n_rows, steps_per_chunk * dim]; out [n_rows, n_chunks * steps_per_chunk, dim] =
+ *   post(cumsum over steps of f(x)),  f = identity (transform 0) | elu(x) + 1 (1) | tanh(x) * pi (2),
+ *   post(s) = s + offset, or 1 / (s + offset) with reciprocal != 0.
+ * Replaces torch.cat + torch.cumsum(dim=-2) + the elementwise ops around them; sums are sequential fp32 adds. */
+int qcn_proposal_cumsum_f32(const float *const *chunks, int n_chunks, int64_t n_rows, int steps_per_chunk, int dim,
+                            int transform, float offset, int reciprocal, float *out, void *stream);
+
 /* G0 / K7 — relative geometry of an edge list (utils/geometry.py:19-23 angle_between_2d_vectors, :47-51 wrap_angle, and
  * their call sites modules/qcnet_map_encoder.py:121-128, qcnet_agent_encoder.py:133-139,161-176, qcnet_decoder.py:161-206):
  *   dp = pos_src[src[e]] - pos_dst[dst[e]];  out[e] = [|dp|, angle(heading_dst, dp), wrap(head_src - head_dst) (, extra[e])]

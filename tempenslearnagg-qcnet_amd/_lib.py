@@ -75,6 +75,8 @@ def _declare(lib) -> None:
     lib.qcn_mlp_heads_pack_floats.argtypes = [c_int]
     lib.qcn_mlp_heads_f32.restype = c_int
     lib.qcn_mlp_heads_f32.argtypes = [P, c_int64, P, c_int, POINTER(c_int), P, P, P, c_int, P]
+    lib.qcn_proposal_cumsum_f32.restype = c_int
+    lib.qcn_proposal_cumsum_f32.argtypes = [P, c_int, c_int64, c_int, c_int, c_int, c_float, c_int, P, P]
     lib.qcn_rel_geometry_f32.restype = c_int
     lib.qcn_rel_geometry_f32.argtypes = [P, c_int, P, c_int, P, P, P, P, P, c_int64, P, P]
     lib.qcn_fourier_linear_f32.restype = c_int
@@ -126,7 +128,7 @@ def _declare(lib) -> None:
 EXPORTED_SYMBOLS = (
     'qcn_version', 'qcn_status_string', 'qcn_radius_count', 'qcn_radius_fill', 'qcn_scan_workspace_bytes',
     'qcn_exclusive_scan_i32', 'qcn_csr_workspace_bytes', 'qcn_csr_build', 'qcn_attn_fwd_f32',
-    'qcn_attn_fused_f32', 'qcn_row_normalize_f32', 'qcn_fourier_pack_floats', 'qcn_fourier_embed_f32', 'qcn_ln_linear_f32', 'qcn_attn_post_pack_floats', 'qcn_attn_post_f32', 'qcn_attn_post_chain_pack_floats', 'qcn_attn_post_chain_f32', 'qcn_gru_f32', 'qcn_attn_modes_bf16_pack_bytes', 'qcn_attn_modes_bf16', 'qcn_gru_pack_floats', 'qcn_fourier_linear_f32', 'qcn_fourier_folded_linear_f32', 'qcn_rel_geometry_f32', 'qcn_mlp_heads_pack_floats', 'qcn_mlp_heads_f32',
+    'qcn_attn_fused_f32', 'qcn_row_normalize_f32', 'qcn_fourier_pack_floats', 'qcn_fourier_embed_f32', 'qcn_ln_linear_f32', 'qcn_attn_post_pack_floats', 'qcn_attn_post_f32', 'qcn_attn_post_chain_pack_floats', 'qcn_attn_post_chain_f32', 'qcn_gru_f32', 'qcn_attn_modes_bf16_pack_bytes', 'qcn_attn_modes_bf16', 'qcn_gru_pack_floats', 'qcn_fourier_linear_f32', 'qcn_fourier_folded_linear_f32', 'qcn_rel_geometry_f32', 'qcn_proposal_cumsum_f32', 'qcn_mlp_heads_pack_floats', 'qcn_mlp_heads_f32',
     'qcn_split_rows_f16', 'qcn_attn_modes_pack_bytes', 'qcn_attn_modes_f32',
     'qcn_attn_modes_store_f32', 'qcn_attn_modes_store_bf16', 'qcn_attn_modes_cached_f32', 'qcn_attn_modes_table_slots', 'qcn_stream_copy', 'qcn_gru_blocked_rows', 'qcn_fourier_gru_input_f32', 'qcn_gru_blocked_f32',
     'qcn_motion_metrics_f32', 'qcn_to_agent_frame_f32', 'qcn_to_world_frame_f32', 'qcn_nms_select_f32',

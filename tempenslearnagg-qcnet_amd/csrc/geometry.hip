@@ -57,3 +57,60 @@ extern "C" int qcn_rel_geometry_f32(const float *pos_src, int pos_stride_src, co
     QCN_CHECK_LAUNCH();
     return QCN_OK;
 }
+
+// ---- proposals of the recurrent steps -> cumulative way-points (modules/qcnet_decoder.py:234-250) ----------------------------
+// The decoder's recurrent proposal steps each emit a chunk of per-step increments [n_rows, steps_per_chunk * dim]; the
+// reference concatenates the chunks and runs  cumsum(x)  (positions),  cumsum(elu(x) + 1) + 0.1  (scales),
+// cumsum(tanh(x) * pi)  (headings),  1 / (cumsum(elu(x) + 1) + 0.02)  (concentrations)  over the step axis: two cats, an
+// outer-dim scan (190 us at 96 000 x 60 x 2 in torch) and three elementwise launches per pair of outputs.  Here: one thread
+// per (row, channel) walks the steps of all chunks — sequential fp32 sums, the order of a CPU cumsum.
+namespace {
+
+struct CumsumChunks {
+    const float *c[4];
+};
+
+__global__ __launch_bounds__(256) void proposal_cumsum_kernel(CumsumChunks ch, int n_chunks, int64_t n_rows, int steps_per_chunk,
+                                                              int dim, int transform, float offset, int reciprocal,
+                                                              float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_rows * dim) return;
+    const int64_t row = i / dim;
+    const int d = (int)(i - row * dim);
+    float acc = 0.0f;
+    float *o = out + row * (int64_t)(n_chunks * steps_per_chunk * dim) + d;
+    for (int c = 0; c < n_chunks; ++c) {
+        const float *src = ch.c[c] + row * (int64_t)(steps_per_chunk * dim) + d;
+        for (int t = 0; t < steps_per_chunk; ++t) {
+            float x = src[t * dim];
+            if (transform == 1) x = __fadd_rn(x > 0.0f ? x : __fsub_rn(expf(x), 1.0f), 1.0f);     // elu(x) + 1
+            else if (transform == 2) x = __fmul_rn(tanhf(x), 3.14159265358979323846f);          // tanh(x) * pi
+            acc = __fadd_rn(acc, x);
+            const float y = __fadd_rn(acc, offset);
+            *o = reciprocal ? __fdiv_rn(1.0f, y) : y;
+            o += dim;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int qcn_proposal_cumsum_f32(const float *const *chunks, int n_chunks, int64_t n_rows, int steps_per_chunk, int dim,
+                                       int transform, float offset, int reciprocal, float *out, void *stream)
+{
+    if (n_chunks < 1 || n_chunks > 4 || n_rows < 0 || steps_per_chunk < 1 || dim < 1 || transform < 0 || transform > 2 || !chunks)
+        return QCN_ERR_INVALID_ARGUMENT;
+    if (n_rows == 0) return QCN_OK;
+    CumsumChunks ch{};
+    for (int c = 0; c < n_chunks; ++c) {
+        if (!chunks[c]) return QCN_ERR_INVALID_ARGUMENT;
+        ch.c[c] = chunks[c];
+    }
+    if (!out) return QCN_ERR_INVALID_ARGUMENT;
+    const int64_t n = n_rows * dim;
+    hipLaunchKernelGGL(proposal_cumsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, qcn_stream(stream), ch, n_chunks,
+                       n_rows, steps_per_chunk, dim, transform, offset, reciprocal, out);
+    QCN_CHECK_LAUNCH();
+    return QCN_OK;
+}

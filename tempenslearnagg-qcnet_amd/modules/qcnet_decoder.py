@@ -291,12 +291,15 @@ class QCNetDecoder(nn.Module):
                                              self._head_cache('propose_head'))
                 hlocs.append(hloc)
                 hconcs.append(hconc)
-        loc_propose_pos = torch.cumsum(torch.cat(locs, dim=-1).view(-1, K, Tf, OD), dim=-2)
-        scale_propose_pos = torch.cumsum(F.elu(torch.cat(scales, dim=-1).view(-1, K, Tf, OD), alpha=1.0) + 1.0,
-                                         dim=-2) + 0.1
+        # cumulative way-points / scales over the future steps (reference :234-250): one launch per output
+        # (qcn_proposal_cumsum_f32) instead of cat + outer-dim scan + elementwise ops
+        flat = lambda chunks: [c.reshape(-1, c.size(-1)) for c in chunks]
+        locs, scales, hlocs, hconcs = flat(locs), flat(scales), flat(hlocs), flat(hconcs)
+        loc_propose_pos = ops.proposal_cumsum(locs, OD).view(-1, K, Tf, OD)
+        scale_propose_pos = ops.proposal_cumsum(scales, OD, ops.CUMSUM_ELU1, 0.1).view(-1, K, Tf, OD)
         if self.output_head:   # reference :243-250: cumulative headings, concentrations; y_emb sees [x, y, wrapped heading]
-            loc_propose_head = torch.cumsum(torch.tanh(torch.cat(hlocs, dim=-1).unsqueeze(-1)) * math.pi, dim=-2)
-            conc_propose_head = 1.0 / (torch.cumsum(F.elu(torch.cat(hconcs, dim=-1).unsqueeze(-1)) + 1.0, dim=-2) + 0.02)
+            loc_propose_head = ops.proposal_cumsum(hlocs, 1, ops.CUMSUM_TANH_PI).view(-1, K, Tf, 1)
+            conc_propose_head = ops.proposal_cumsum(hconcs, 1, ops.CUMSUM_ELU1, 0.02, reciprocal=True).view(-1, K, Tf, 1)
             y_in = torch.cat([loc_propose_pos.detach(), wrap_angle(loc_propose_head.detach())], dim=-1)
         else:
             loc_propose_head = loc_propose_pos.new_zeros((A, K, Tf, 1))

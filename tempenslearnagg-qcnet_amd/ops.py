@@ -729,6 +729,38 @@ def _rel_geometry(pos_src, pos_dst, head_src, head_dst, edge_index, extra):
     return out
 
 
+CUMSUM_IDENTITY, CUMSUM_ELU1, CUMSUM_TANH_PI = 0, 1, 2
+
+
+def proposal_cumsum(chunks: Sequence[torch.Tensor], dim: int, transform: int = CUMSUM_IDENTITY, offset: float = 0.0,
+                    reciprocal: bool = False) -> torch.Tensor:
+    """qcn_proposal_cumsum_f32: ``post(cumsum_t f(cat(chunks, -1).view(n, -1, dim)))`` -> [n, steps, dim]; chunks
+    [n, steps_per_chunk * dim] each (the per-step increments one recurrent proposal step emits)."""
+    return _op('proposal_cumsum')(list(chunks), int(dim), int(transform), float(offset), bool(reciprocal))
+
+
+def _proposal_cumsum_fake(chunks, dim, transform, offset, reciprocal):
+    n, w = chunks[0].shape
+    return chunks[0].new_empty((n, len(chunks) * (w // dim), dim))
+
+
+@_register('proposal_cumsum', '(Tensor[] chunks, int dim, int transform, float offset, bool reciprocal) -> Tensor', _proposal_cumsum_fake)
+def _proposal_cumsum(chunks, dim, transform, offset, reciprocal):
+    if not 1 <= len(chunks) <= 4:
+        raise ValueError('1..4 chunks')
+    dev = chunks[0].device
+    n, w = chunks[0].shape
+    if dim < 1 or w % dim:
+        raise ValueError('chunk width %d is not a multiple of dim %d' % (w, dim))
+    for i, c in enumerate(chunks):
+        _require(c, 'chunks[%d]' % i, torch.float32, dev, (n, w))
+    out = torch.empty(n, len(chunks) * (w // dim), dim, dtype=torch.float32, device=dev)
+    ptrs = (ctypes.c_void_p * len(chunks))(*[c.data_ptr() for c in chunks])
+    _lib.check(_lib.lib().qcn_proposal_cumsum_f32(ptrs, len(chunks), n, w // dim, int(dim), int(transform), float(offset),
+                                                  int(bool(reciprocal)), _ptr(out), _stream(dev)), 'qcn_proposal_cumsum_f32')
+    return out
+
+
 def pack_mlp_heads(heads, mode: Optional[int] = None) -> torch.Tensor:
     """Pack for qcn_mlp_heads_f32 from a list of (w1 [128,128], b1, ln_w, ln_b, w2 [out,128], b2 [out]) tuples."""
     mats, vecs = [], []

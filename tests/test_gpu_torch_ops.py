@@ -156,6 +156,23 @@ def test_op_attn_post_chain(mode, n_next, n_rows):
         assert rel_err(outs[1 + j], wn @ nw[j].t() + nb[j]) < (2e-2 if mode == ops.MATMUL_BF16 else 2e-5)
 
 
+def test_op_proposal_cumsum():
+    """qcn_proposal_cumsum_f32 against the torch forms of modules/qcnet_decoder.py:234-250."""
+    import math
+    chunks = [_rand(333, 40, seed=200 + i).to(DEV) for i in range(3)]
+    x = torch.cat([c.cpu() for c in chunks], dim=-1).view(333, 60, 2)
+    got = op('proposal_cumsum')(chunks, 2, ops.CUMSUM_IDENTITY, 0.0, False)
+    assert tuple(got.shape) == (333, 60, 2) and rel_err(got, torch.cumsum(x, dim=-2)) < 2e-6
+    got = op('proposal_cumsum')(chunks, 2, ops.CUMSUM_ELU1, 0.1, False)
+    assert rel_err(got, torch.cumsum(F.elu(x) + 1.0, dim=-2) + 0.1) < 2e-6
+    heads = [_rand(77, 20, seed=210 + i).to(DEV) for i in range(3)]
+    xh = torch.cat([c.cpu() for c in heads], dim=-1).unsqueeze(-1)
+    got = op('proposal_cumsum')(heads, 1, ops.CUMSUM_TANH_PI, 0.0, False)
+    assert tuple(got.shape) == (77, 60, 1) and rel_err(got, torch.cumsum(torch.tanh(xh) * math.pi, dim=-2)) < 2e-6
+    got = op('proposal_cumsum')(heads, 1, ops.CUMSUM_ELU1, 0.02, True)
+    assert rel_err(got, 1.0 / (torch.cumsum(F.elu(xh) + 1.0, dim=-2) + 0.02)) < 2e-6
+
+
 def test_op_fourier_embed_and_fourier_linear():
     m = FourierEmbedding(input_dim=2, hidden_dim=128, num_freq_bands=64).eval().to(DEV)
     with torch.no_grad():
