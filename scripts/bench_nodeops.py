@@ -34,6 +34,10 @@ with torch.no_grad():
         ms = timeit(lambda: ops.attn_post(x[0], x[1], x[2], x[3], packs['post']))
         print('attn_post  rows %8d  %9.1f us  %6.1f TF/s' % (n, ms * 1e3, n * 11 * 32768 / ms * 1e-9))
         ln = layer.attn_prenorm_x_src
+        for n_next, key in ((0, None), (1, 'pre_q'), (3, 'pre_qkv')):
+            nx = (None, None, None, None) if key is None else packs[key] + (ln.weight, ln.bias)
+            ms = timeit(lambda: ops.attn_post_chain(x[0], x[3], packs['post_chain'], *nx))
+            print('attn_post_chain+%d rows %8d  %9.1f us  %6.1f TF/s' % (n_next, n, ms * 1e3, n * (12 + n_next) * 32768 / ms * 1e-9))
         ms = timeit(lambda: ops.ln_linear(x[0], ln.weight, ln.bias, *packs['pre_all'], want_xn=True))
         print('ln_linear4 rows %8d  %9.1f us  %6.1f TF/s' % (n, ms * 1e3, n * 4 * 32768 / ms * 1e-9))
         for d in (2, 3, 4):
