@@ -307,7 +307,7 @@ def main() -> None:
     # on a known byte count in the kernel's own access width: scripts/pmc_workload.py, scripts/pmc_summary.py); the
     # counters cannot be read from inside this process, so the committed summary of the same workload is quoted.
     traffic = None
-    for name in ('r2_final_pmc_attention.json', 'r2_pmc_attention.json', 'r1_x_pmc_attention.json'):
+    for name in ('r3_pmc_attention.json', 'r2_final_pmc_attention.json', 'r2_pmc_attention.json', 'r1_x_pmc_attention.json'):
         pmc_file = os.path.join(ROOT, 'profiles', name)
         if args.config == 'cfg3' and batch_size == cfg['batch'] and mode == ops.MATMUL_SPLIT_F16 and os.path.exists(pmc_file):
             with open(pmc_file) as fh:

@@ -4,7 +4,7 @@ summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; GRB
 import collections, csv, glob, json, sys
 
 f = (glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*counter_collection.csv'))[0]
-FAMILIES = ('attn_modes_kernel', 'attn_fused_kernel', 'attn_fwd_kernel', 'fourier_kernel', 'attn_post_kernel', 'ln_linear_kernel',
+FAMILIES = ('attn_modes_kernel', 'attn_kv_kernel', 'attn_fused_kernel', 'attn_fwd_kernel', 'fourier_pair_kernel', 'fourier_kernel', 'attn_post_kernel', 'ln_linear_kernel',
             'gru_split_kernel', 'mlp_heads_kernel')
 rows = collections.defaultdict(lambda: collections.defaultdict(list))       # family -> counter -> per-dispatch values
 for r in csv.DictReader(open(f)):
