@@ -212,6 +212,41 @@ def test_fast_path_switches_do_not_change_predictions():
         assert rel_err(first[k], fused[k]) < 1e-5, k
 
 
+def test_fallback_branches_give_the_default_path_s_predictions():
+    """The switches behind the default path (they are read at import time, so their fallback branches never ran
+    under pytest): TemporalAggregate's proposal half behind the ten-frame pass instead of beside it, the per-edge projection
+    tables off (recomputation), the heavy Fourier launches left on the preparation stream, the GRU input halves row-major —
+    each only moves work or re-does the same arithmetic: BIT-IDENTICAL predictions.  The unchained node side
+    (qcn_ln_linear_f32 + qcn_attn_post_f32 instead of qcn_attn_post_chain_f32) adds its biases in another order: 1e-5."""
+    from tempenslearnagg_qcnet_amd.layers import attention_layer
+    from tempenslearnagg_qcnet_amd.modules import qcnet_decoder
+    from tempenslearnagg_qcnet_amd.utils import prep
+    cfg = config_scene('tiny')
+    model = _model(cfg, seed=7).to(DEV)
+    batch = make_batch([0, 1, 2], **cfg['scene']).to(DEV)
+    keys = ('traj_refine', 'pi_softmax', 'final_m')
+    flips = [(model, 'overlap_aggregate', False), (attention_layer, 'CACHE_EDGE_PROJECTIONS', False), (prep, 'DEFER_HEAVY', False),
+             (qcnet_decoder, 'BLOCKED_GRU_INPUT', False)]
+    with torch.no_grad():
+        want = model.predict(batch)
+        for obj, name, value in flips:
+            old = getattr(obj, name)
+            setattr(obj, name, value)
+            try:
+                got = model.predict(batch)
+            finally:
+                setattr(obj, name, old)
+            for k in keys:
+                assert torch.equal(got[k], want[k]), (name, k)
+        try:
+            attention_layer.CHAIN_NODE_SIDE = False
+            got = model.predict(batch)
+        finally:
+            attention_layer.CHAIN_NODE_SIDE = True
+        for k in keys:
+            assert rel_err(got[k], want[k]) < 1e-5, k
+
+
 def test_back_to_back_batches_overlap_without_changing_predictions():
     """Cross-batch overlap (utils/prep.py: the preparation stream waits for a batch's ready mark, not for the main
     stream): different batches predicted back to back without any host synchronisation, at a size whose kernels run long
