@@ -140,6 +140,8 @@ def inputs_ready(device: torch.device, data=None, module=None) -> None:
     in-place update since.  In every other case the side stream waits for everything enqueued on the current stream."""
     if MEMO:
         _memo_key[0], _memo_key[1] = (id(data) if data is not None else None), 0
+        if data is not None:
+            _memo_batches[id(data)] = data
     if ENABLED and device.type == 'cuda':
         event = None
         if data is not None and os.environ.get('QCN_PREP_WAIT_MAIN', '0') == '0':
@@ -166,13 +168,25 @@ def defer(fn: Callable[[], None], inputs=()) -> None:
         fn()
 
 
-# Diagnostic (QCN_PREP_MEMO=1, bench runs that cycle over a few resident batches): the results of a batch's sections are kept
-# and handed out again when the same batch object comes back — the small launches and host round trips of the sections
-# disappear, the deferred heavy launches still run.  Upper bound of what moving the graph builders into a few fused kernels
-# could gain; never set it where a batch's tensors change between calls.
+# Prepared batches (``memoize_sections(True)`` / QCN_PREP_MEMO=1): the results of a batch's sections are kept and handed out
+# again when the SAME batch object is predicted again — the small launches and the host round trips of the graph
+# construction happen once, every later call is pure launches on device-resident graphs (the deferred heavy launches still
+# run).  That is what makes a call capturable into a HIP graph (tests/test_gpu_model.py::
+# test_captured_step_replays_bit_identically) and what `bench.py`-style runs over a few resident batches use to price the
+# preparation work.  Contract: the batch's tensors and the model's weights do not change while the results
+# are kept; ``memoize_sections(False)`` drops them.  Not thread-safe across host threads that share batch objects.
 MEMO = os.environ.get('QCN_PREP_MEMO', '0') != '0'
 _memo: Dict[tuple, tuple] = {}
 _memo_key = [None, 0]
+_memo_batches: Dict[int, object] = {}      # the batch objects themselves: a kept batch's id() cannot be reused by another
+
+
+def memoize_sections(on: bool) -> None:
+    global MEMO
+    MEMO = bool(on)
+    _memo.clear()
+    _memo_batches.clear()
+    _memo_key[0], _memo_key[1] = None, 0
 
 
 def run_prep(device: torch.device, fn: Callable[[], object]):

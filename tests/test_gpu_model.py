@@ -247,6 +247,37 @@ def test_fallback_branches_give_the_default_path_s_predictions():
             assert rel_err(got[k], want[k]) < 1e-5, k
 
 
+def test_captured_step_replays_bit_identically():
+    """A full predict (ten frames + aggregate, three streams) of a PREPARED batch — its graph construction done once, eagerly
+    (utils/prep.py::memoize_sections) — is pure launches: captured into a HIP graph and replayed it gives the eager call's
+    bits.  (A graph that serves NEW batches needs the graph builders on the device with upper-bound buffers: DESIGN.md §7.)"""
+    from tempenslearnagg_qcnet_amd.utils import prep
+    cfg = config_scene('tiny')
+    model = _model(cfg, seed=9).to(DEV)
+    batch = make_batch([0, 1, 2], **cfg['scene']).to(DEV)
+    keys = ('traj_refine', 'pi_softmax', 'final_m')
+    stream = torch.cuda.Stream(device=DEV)
+    prep.memoize_sections(True)
+    try:
+        with torch.no_grad(), torch.cuda.stream(stream):
+            want = model.predict(batch)                 # builds and keeps the batch's graphs, warms every kernel
+            want = {k: model.predict(batch)[k].clone() for k in keys}
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                got = model.predict(batch)
+            torch.cuda.synchronize()
+            for _ in range(2):
+                for k in keys:
+                    got[k].zero_()
+                graph.replay()
+                torch.cuda.synchronize()
+                for k in keys:
+                    assert torch.equal(got[k], want[k]), k
+    finally:
+        prep.memoize_sections(False)
+
+
 def test_back_to_back_batches_overlap_without_changing_predictions():
     """Cross-batch overlap (utils/prep.py: the preparation stream waits for a batch's ready mark, not for the main
     stream): different batches predicted back to back without any host synchronisation, at a size whose kernels run long
