@@ -326,16 +326,24 @@ int qcn_attn_post_f32(const float *agg, const float *xn_dst, const float *s_proj
  *     or attn_prenorm_x_src + to_q / to_k / to_v of a layer over one node set (n_next = 3), layers/attention_layer.py:74-79 of
  *     the following call — applied to the output row before it leaves the registers: that layer then needs no
  *     qcn_ln_linear_f32 launch for its destination rows.  next_wt / next_bias: the qcn_ln_linear_f32 layout (n_next
- *     chain-packed matrices + their scale pairs; [n_next,128] or NULL); next_ln_weight / next_ln_bias: [128].
+ *     chain-packed matrices + their scale pairs; [n_next,128] or NULL); next_ln_weight / next_ln_bias: [128], plain;
+ *     next_operand_scale (split mode): the power of two that puts the bound sqrt(127) max|gamma| + max|beta| of LN_next's
+ *     output at 2^15 (its static operand scale; the kernel folds it into gamma / beta), or <= 0: per-row maxima.
  * pack (qcn_attn_post_chain_pack_floats() floats): 12 chain-packed matrices [to_g.weight[:, :128], to_g.weight[:, 128:],
  *   to_s.weight, to_out.weight, then the eight feed-forward blocks as above], the vectors of qcn_attn_post_f32's pack,
- *   to_s.bias, the scale table (32 floats).  Same arithmetic per element as qcn_ln_linear_f32 + qcn_attn_post_f32.
+ *   to_s.bias, the scale table (32 floats: 12 {scale, 1 / scale} pairs, then {s_pre, 1 / s_pre, s_ff, 1 / s_ff, 1 / P}).
+ *   Split mode: attn_prenorm_x_dst's and ff_prenorm's gamma / beta arrive multiplied by the static operand scales s_pre /
+ *   s_ff of their outputs, ff_mlp.0.bias block hb by the hidden block's static scale s_h[hb], the 1 / scale slot of
+ *   ff_mlp.0's block hb by s_h[hb] as well, and the four ff_mlp.3 blocks are packed with matrix scales P / s_h[hb]
+ *   (host: ops.pack_attn_post_chain; bounds: |LN(x)| <= sqrt(127) max|gamma| + max|beta|, hidden through the L1 norms of the
+ *   weight rows).  Other modes: plain parameters, table padded with ones.
+ *   Same arithmetic per element as qcn_ln_linear_f32 + qcn_attn_post_f32 up to the operand scales (22-bit operands either way).
  *   out and y_j must not alias an input or each other.  Runs in blocks of at most four waves (one wave per SIMD). */
 size_t qcn_attn_post_chain_pack_floats(void);
 int qcn_attn_post_chain_f32(const float *agg, const float *x_res, const float *pack, int64_t n_rows, float *out,
                             const float *next_wt, const float *next_bias, const float *next_ln_weight,
-                            const float *next_ln_bias, int n_next, float *y0, float *y1, float *y2, int matmul_mode,
-                            void *stream);
+                            const float *next_ln_bias, float next_operand_scale, int n_next, float *y0, float *y1, float *y2,
+                            int matmul_mode, void *stream);
 
 /* M4 glue — the cumulative way-points of the decoder's recurrent proposal steps (modules/qcnet_decoder.py:234-250): chunk c
  * (c < n_chunks <= 4, host array of device pointers) holds the increments of steps [c * steps_per_chunk, (c + 1) *

@@ -49,3 +49,9 @@ for name, a, b in sorted(ranges, key=lambda r: r[1]):
     n = sum(1 for e in launch if a <= e.time_range.start <= b)
     c = collections.Counter(e.name for e in ops_ if a <= e.time_range.start <= b and e.cpu_parent is not None and e.cpu_parent.name.startswith('PREP:'))
     print('%-50s %4d launches, %6.2f ms host; top-level ops: %s' % (name, n, (b - a) / 1e3, ', '.join('%s x%d' % kv for kv in c.most_common(40))))
+    # GPU time of the section's top-level ops (their kernels, whichever stream they ran on)
+    g = collections.Counter()
+    for e in ops_:
+        if a <= e.time_range.start <= b and e.cpu_parent is not None and e.cpu_parent.name.startswith('PREP:'):
+            g[e.name] += getattr(e, 'device_time_total', None) or getattr(e, 'cuda_time_total', 0)
+    print('%-50s GPU us by op: %s' % ('', ', '.join('%s %.0f' % kv for kv in g.most_common(14))))

@@ -66,7 +66,7 @@ def _declare(lib) -> None:
     lib.qcn_attn_post_chain_pack_floats.restype = c_size_t
     lib.qcn_attn_post_chain_pack_floats.argtypes = []
     lib.qcn_attn_post_chain_f32.restype = c_int
-    lib.qcn_attn_post_chain_f32.argtypes = [P, P, P, c_int64, P, P, P, P, P, c_int, P, P, P, c_int, P]
+    lib.qcn_attn_post_chain_f32.argtypes = [P, P, P, c_int64, P, P, P, P, P, c_float, c_int, P, P, P, c_int, P]
     lib.qcn_gru_f32.restype = c_int
     lib.qcn_gru_f32.argtypes = [P, P, P, P, P, P, c_int64, c_int, P, c_int, P]
     lib.qcn_row_normalize_f32.restype = c_int

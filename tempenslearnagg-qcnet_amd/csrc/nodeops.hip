@@ -89,6 +89,7 @@ struct PostNext {
     const float *ln_g, *ln_b;
     float *y[3];
     int n;                  // 0: no next-layer projections
+    float sc;               // split mode: static operand scale of LN_next's output (a power of two; <= 0: row maxima instead)
 };
 
 #ifdef QCN_CHAIN_STAMPS
@@ -124,9 +125,31 @@ __device__ __forceinline__ void hid_load(HidSteps &S, const float *bias, int h, 
 
 // steps 0..7: y = relu(a * U + b) (two groups per step) and four running maxima; 8, 9: row maximum -> power-of-two scale
 // (make_operand's rule); 10..25: one group per step scaled and split into the operand
+// STATIC (the chained form): U and the bias carry the hidden block's static operand scale (host: ops.pack_attn_post_chain),
+// so y arrives scaled — no row maximum, no scaling multiply: steps 0..7 y = relu(a * U + b), 10..25 the split.
+template <bool STATIC = false>
 __device__ __forceinline__ void hid_step(f32x16 (&a)[4], float U, Operand<kModeSplit> &hid, HidSteps &S, int g, const f32x4 c0,
                                          const f32x4 c1)
 {
+    if constexpr (STATIC) {
+        if (g < 8) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = 2 * g + i, t = m >> 2, q = m & 3;
+                const f32x4 c = i ? c1 : c0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float y = fmaxf(fmaf(a[t][4 * q + k], U, c[k]), 0.f);
+                    pin(y);
+                    a[t][4 * q + k] = y;
+                }
+            }
+        } else if (g >= 10 && g < 26) {
+            const int m = g - 10, t = m >> 2, q = m & 3;
+            put4(hid, t, q, grp(a, t, q));
+        }
+        return;
+    }
     if (g < 8) {
         if (g == 0) {
 #pragma unroll
@@ -207,6 +230,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
 {
     static_assert(!CHAIN || WAVES <= 4, "the chained form holds the s projection in registers: one wave per SIMD");
     constexpr int kVecFloats = (CHAIN ? kChainVecs : kPostVecs) + kPostScales + (CHAIN ? kNextVecs : 0);
+    constexpr bool kStaticNext = CHAIN && MODE == kModeSplit;
     constexpr int kMats = CHAIN ? kChainMats : kPostMats;
     constexpr int kM = CHAIN ? 1 : 0;            // matrices behind Wg_x move up by one (Ws)
     __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + kVecFloats / 4 + WAVES * 128];
@@ -224,6 +248,10 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     const float *nvec = msc + kPostScales;     // CHAIN: ln_g, ln_b, biases of the next layer's projections
     const float eps = 1e-5f;
     Operand<MODE> op;
+    // Chained split form: LayerNorm outputs and the hidden blocks are STATIC-scale operands — the host folded their power-of-two
+    // scales into gamma / beta / b1 and into the scale table (ops.pack_attn_post_chain; table slots 24.. = {s_pre, 1 / s_pre,
+    // s_ff, 1 / s_ff, 1 / P}), and the four second-layer GEMMs accumulate raw in ONE scale P.
+    constexpr bool kStatic = CHAIN && MODE == kModeSplit;
     // the matrices alternate between the two buffers; behind Ws the parity flips
     f32x4 *const bA = CHAIN ? wlds : wlds + kMatVec4, *const bB = CHAIN ? wlds + kMatVec4 : wlds;
 
@@ -236,7 +264,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
     if constexpr (CHAIN) {
         if (next.n > 0) {
             float *nv = svec + kChainVecs + kPostScales;
-            for (int i = tid; i < kC; i += 64 * WAVES) { nv[i] = next.ln_g[i]; nv[kC + i] = next.ln_b[i]; }
+            const float nsc_ln = kStaticNext && next.sc > 0.f ? next.sc : 1.0f;     // folded into gamma / beta
+            for (int i = tid; i < kC; i += 64 * WAVES) { nv[i] = next.ln_g[i] * nsc_ln; nv[kC + i] = next.ln_b[i] * nsc_ln; }
             for (int i = tid; i < next.n * kC; i += 64 * WAVES) nv[2 * kC + i] = next.bias != nullptr ? next.bias[i] : 0.f;
         }
     }
@@ -267,7 +296,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
             }
             layer_norm<true, false>(vx, vec + kVPreG, vec + kVPreB, h, eps);
         }
-        make_operand(op, vx);
+        if constexpr (kStatic) make_operand_static(op, vx, msc[24], msc[25]);
+        else make_operand(op, vx);
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
         gemm<WAVES>(acc, op, buf1, msc + 2, lane, mats + 2 * kMatFloats, buf0, wave);
         skew_after_gemm(skew); PSTAMP(2)
@@ -309,9 +339,11 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = xr[t];
     layer_norm<true, false>(acc, vec + kVLfG, vec + kVLfB, h, eps);
-    make_operand(op, acc);
+    if constexpr (kStatic) make_operand_static(op, acc, msc[26], msc[27]);
+    else make_operand(op, acc);
     f32x16 acc_o[4];
-    load_feature_vec(acc_o, vec + kVB2, h);
+    if constexpr (kStatic) fill_zero(acc_o);                  // raw sum of the four second-layer GEMMs; bias and scale at the end
+    else load_feature_vec(acc_o, vec + kVB2, h);
     constexpr bool kPipelined = MODE == kModeSplit && WAVES <= 4;
     if constexpr (kPipelined) {
         auto W1 = [&](int hb) { return mats + (size_t)(3 + kM + 2 * hb) * kMatFloats; };
@@ -330,12 +362,13 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
             hid_load(S, bias, h, 0);
             PSTAMP(0) sync_for_stage(); PSTAMP(1)
             gemm_steps<WAVES>(an, op, wb, lane, nx, nb, wave, S, [&](int g) { hid_load(S, bias, h, g); },
-                              [&](int g, const f32x4 c0, const f32x4 c1) { hid_step(ap, U, hid, S, g, c0, c1); });
+                              [&](int g, const f32x4 c0, const f32x4 c1) { hid_step<kStatic>(ap, U, hid, S, g, c0, c1); });
             PSTAMP(2)
         };
         auto g2 = [&](int hb, f32x4 *wb, const float *nx, f32x4 *nb) {
             PSTAMP(0) sync_for_stage(); PSTAMP(1)
-            gemm<WAVES>(acc_o, hid, wb, msc + 2 * (4 + kM + 2 * hb), lane, nx, nb, wave);
+            if constexpr (kStatic) gemm_raw<WAVES, MODE>(acc_o, hid, wb, lane, nx, nb, wave);
+            else gemm<WAVES>(acc_o, hid, wb, msc + 2 * (4 + kM + 2 * hb), lane, nx, nb, wave);
             PSTAMP(2)
         };
         fill_zero(a0);
@@ -356,10 +389,11 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
             for (int g = 0; g < 26; ++g) {
                 const f32x4 c0 = S.b0, c1 = S.b1;
                 hid_load(S, bias, h, g + 1);
-                hid_step(a1, U, hid, S, g, c0, c1);
+                hid_step<kStatic>(a1, U, hid, S, g, c0, c1);
             }
         }
         g2(3, bB, after, bA);                                                         // W2_3
+        if constexpr (kStatic) scale_add(acc_o, msc[28], BiasTerm{vec + kVB2, h});
     } else {
     const float *after = CHAIN && next.n > 0 ? next.wt : nullptr;
 #pragma unroll 1
@@ -390,7 +424,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         // for a layer over one node set): qcn_ln_linear_f32's arithmetic on the row it would have read back
         if (next.n > 0) {
             layer_norm<true, false>(acc_o, nvec, nvec + kC, h, eps);
-            make_operand(op, acc_o);
+            if (kStaticNext && next.sc > 0.f) make_operand_static(op, acc_o, next.sc, 1.0f / next.sc);
+            else make_operand(op, acc_o);
             const float *nsc = next.wt + (size_t)next.n * kMatFloats;
 #pragma unroll 1
             for (int j = 0; j < next.n; ++j) {
@@ -525,8 +560,8 @@ extern "C" size_t qcn_attn_post_chain_pack_floats(void) { return (size_t)kChainM
 
 extern "C" int qcn_attn_post_chain_f32(const float *agg, const float *x_res, const float *pack, int64_t n_rows, float *out,
                                        const float *next_wt, const float *next_bias, const float *next_ln_weight,
-                                       const float *next_ln_bias, int n_next, float *y0, float *y1, float *y2, int matmul_mode,
-                                       void *stream)
+                                       const float *next_ln_bias, float next_operand_scale, int n_next, float *y0, float *y1,
+                                       float *y2, int matmul_mode, void *stream)
 {
     if (n_rows < 0 || n_next < 0 || n_next > 3 || !valid_mode(matmul_mode)) return QCN_ERR_INVALID_ARGUMENT;
     if (n_rows == 0) return QCN_OK;
@@ -540,7 +575,7 @@ extern "C" int qcn_attn_post_chain_f32(const float *agg, const float *x_res, con
     int waves = pick_waves(n_rows, 0.9);
     if (waves > 4) waves = 4;
     const unsigned grid = (unsigned)((n_rows + 32 * waves - 1) / (32 * waves));
-    const PostNext next{next_wt, next_bias, next_ln_weight, next_ln_bias, {y0, y1, y2}, n_next};
+    const PostNext next{next_wt, next_bias, next_ln_weight, next_ln_bias, {y0, y1, y2}, n_next, next_operand_scale};
 #define QCN_LAUNCH_C(M)                                                                                                     \
     do {                                                                                                                    \
         if (waves == 4)                                                                                                     \

@@ -193,6 +193,10 @@ class AttentionLayer(nn.Module):
                                 torch.stack([self.to_q.bias, zero, self.to_v.bias, self.to_s.bias]).contiguous())
             # chained node side (qcn_attn_post_chain_f32 computes s): what is left for qcn_ln_linear_f32 / the previous layer
             packs['pre_q'] = (stack(self.to_q), self.to_q.bias.reshape(1, C).contiguous())
+            # static operand scale of the LayerNorm output in front of the destination-side projections (the previous layer's
+            # node-side kernel applies them in a chained stack)
+            ln_d = self.attn_prenorm_x_dst if self.bipartite else self.attn_prenorm_x_src
+            packs['dst_operand_scale'] = ops.static_operand_scale(ops.layer_norm_bound(ln_d.weight, ln_d.bias))
             packs['pre_qkv'] = (stack(self.to_q, self.to_k, self.to_v),
                                 torch.stack([self.to_q.bias, zero, self.to_v.bias]).contiguous())
             w1, w2 = self.ff_mlp[0], self.ff_mlp[3]
@@ -202,12 +206,14 @@ class AttentionLayer(nn.Module):
             vecs = [self.to_g.bias, self.to_out.bias, self.attn_postnorm.weight, self.attn_postnorm.bias,
                     self.ff_prenorm.weight, self.ff_prenorm.bias, w1.bias, w2.bias, self.ff_postnorm.weight,
                     self.ff_postnorm.bias, self.attn_prenorm_x_dst.weight, self.attn_prenorm_x_dst.bias]
-            for name, head, tail in (('post', [self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_out.weight], []),
-                                     ('post_chain', [self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_s.weight,
-                                                     self.to_out.weight], [self.to_s.bias])):
-                mats, scales = ops.pack_chain_set(head + ffn, mode=mode)
-                packs[name] = torch.cat([mats.reshape(-1)] + [v.reshape(-1).float() for v in vecs + tail]
-                                        + [ops.scale_table(scales)]).contiguous()
+            mats, scales = ops.pack_chain_set([self.to_g.weight[:, :C], self.to_g.weight[:, C:], self.to_out.weight] + ffn, mode=mode)
+            packs['post'] = torch.cat([mats.reshape(-1)] + [v.reshape(-1).float() for v in vecs]
+                                      + [ops.scale_table(scales)]).contiguous()
+            ln = lambda m: (m.weight, m.bias)
+            packs['post_chain'] = ops.pack_attn_post_chain(
+                self.to_g.weight, self.to_g.bias, self.to_s.weight, self.to_s.bias, self.to_out.weight, self.to_out.bias,
+                w1.weight, w1.bias, w2.weight, w2.bias, ln(self.attn_postnorm), ln(self.ff_prenorm), ln(self.ff_postnorm),
+                ln(self.attn_prenorm_x_dst), mode=mode)
             if self.has_pos_emb:
                 gamma, beta = self.attn_prenorm_r.weight, self.attn_prenorm_r.bias
                 packs['pos'] = ((self.to_k_r.weight * gamma.unsqueeze(0)).contiguous(),
@@ -340,7 +346,8 @@ class AttentionLayer(nn.Module):
         if next_layer is None:
             return ops.attn_post_chain(agg, x_res, packs['post_chain'], mode=mode)[0]
         nwt, nbias, nln = next_layer._destination_projection()
-        outs = ops.attn_post_chain(agg, x_res, packs['post_chain'], nwt, nbias, nln.weight, nln.bias, mode=mode)
+        outs = ops.attn_post_chain(agg, x_res, packs['post_chain'], nwt, nbias, nln.weight, nln.bias, mode=mode,
+                                   next_operand_scale=next_layer._kernel_packs()['dst_operand_scale'])
         return outs[0], tuple(outs[1:])
 
     def _destination_projection(self):

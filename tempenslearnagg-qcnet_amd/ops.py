@@ -645,23 +645,79 @@ def _attn_post(agg, xn_dst, s_proj, x_res, pack, mode):
     return out
 
 
+def pack_attn_post_chain(to_g_w: torch.Tensor, to_g_b: torch.Tensor, to_s_w: torch.Tensor, to_s_b: torch.Tensor,
+                         to_out_w: torch.Tensor, to_out_b: torch.Tensor, ff1_w: torch.Tensor, ff1_b: torch.Tensor,
+                         ff2_w: torch.Tensor, ff2_b: torch.Tensor, postnorm, ff_prenorm, ff_postnorm, prenorm_dst,
+                         mode: Optional[int] = None) -> torch.Tensor:
+    """The ``pack`` of qcn_attn_post_chain_f32 (include/qcnet_hip.h) from the parameters of one AttentionLayer
+    (layers/attention_layer.py:44-61): ``to_g`` [128, 256], ``to_s`` / ``to_out`` [128, 128], ``ff_mlp.0`` [512, 128], ``ff_mlp.3``
+    [128, 512] and the four LayerNorms as (weight, bias) pairs.
+    Split mode: the LayerNorm outputs and the hidden blocks are STATIC-scale operands of the kernel — |LN(x)| <= sqrt(127)
+    max|gamma| + max|beta| and |relu(W1 y + b1)| <= max_j (sum_k |W1_jk| bound(y) + |b1_j|) hold for every input, so the powers of
+    two that put those bounds at 2^15 are folded into gamma / beta / b1 and the scale table here (no row maximum, no scaling
+    multiply in the kernel), and the four second-layer matrices get matrix scales that make (hidden scale x matrix scale) ONE
+    value P: their products accumulate raw, the way back is one fma with the bias."""
+    mode = _mode(mode)
+    f = lambda t: t.detach().float()
+    wg, w1, w2, b1 = f(to_g_w), f(ff1_w), f(ff2_w), f(ff1_b)
+    heads = [wg[:, :C], wg[:, C:], f(to_s_w), f(to_out_w)]
+    ffn = []
+    for hb in range(4):
+        ffn += [w1[hb * C:(hb + 1) * C, :], w2[:, hb * C:(hb + 1) * C]]
+    pre_g, pre_b = f(prenorm_dst[0]), f(prenorm_dst[1])
+    lf_g, lf_b = f(ff_prenorm[0]), f(ff_prenorm[1])
+    extra = torch.ones(8, dtype=torch.float32, device=wg.device)
+    if mode == MATMUL_SPLIT_F16:
+        s_pre = static_operand_scale(layer_norm_bound(pre_g, pre_b))
+        bound_ff = layer_norm_bound(lf_g, lf_b)
+        s_ff = static_operand_scale(bound_ff)
+        s_h = []
+        for hb in range(4):
+            rows = w1[hb * C:(hb + 1) * C, :]
+            bound = 1.01 * float((rows.abs().sum(dim=1) * bound_ff + b1[hb * C:(hb + 1) * C].abs()).max())
+            s_h.append(static_operand_scale(bound))
+        p_common = min(s_h[hb] * split_matrix_scale(ffn[2 * hb + 1]) for hb in range(4))
+        pairs = [pack_chain_matrix(w, mode=mode) for w in heads]
+        for hb in range(4):
+            m1, sc1 = pack_chain_matrix(ffn[2 * hb], mode=mode)
+            sc1 = sc1.clone()
+            sc1[1] = sc1[1] * s_h[hb]            # the way back from the first layer lands in the hidden block's operand scale
+            pairs += [(m1, sc1), pack_chain_matrix(ffn[2 * hb + 1], mode=mode, scale=p_common / s_h[hb])]
+        pre_g, pre_b, lf_g, lf_b = pre_g * s_pre, pre_b * s_pre, lf_g * s_ff, lf_b * s_ff
+        b1 = torch.cat([b1[hb * C:(hb + 1) * C] * s_h[hb] for hb in range(4)])
+        extra = torch.tensor([s_pre, 1.0 / s_pre, s_ff, 1.0 / s_ff, 1.0 / p_common, 1.0, 1.0, 1.0], dtype=torch.float32,
+                             device=wg.device)
+    else:
+        pairs = [pack_chain_matrix(w, mode=mode) for w in heads + ffn]
+    mats = torch.stack([p[0] for p in pairs])
+    scales = torch.stack([p[1] for p in pairs]).reshape(-1)                    # 24 floats
+    vecs = [to_g_b, to_out_b, postnorm[0], postnorm[1], lf_g, lf_b, b1, ff2_b, ff_postnorm[0], ff_postnorm[1], pre_g, pre_b,
+            to_s_b]
+    out = torch.cat([mats.reshape(-1)] + [f(v).reshape(-1) for v in vecs] + [scales, extra]).contiguous()
+    assert out.numel() == int(_lib.lib().qcn_attn_post_chain_pack_floats())
+    return out
+
+
 def attn_post_chain(agg: torch.Tensor, x_res: torch.Tensor, pack: torch.Tensor, next_wt: Optional[torch.Tensor] = None,
                     next_bias: Optional[torch.Tensor] = None, next_ln_weight: Optional[torch.Tensor] = None,
-                    next_ln_bias: Optional[torch.Tensor] = None, mode: Optional[int] = None) -> List[torch.Tensor]:
+                    next_ln_bias: Optional[torch.Tensor] = None, mode: Optional[int] = None,
+                    next_operand_scale: float = 0.0) -> List[torch.Tensor]:
     """qcn_attn_post_chain_f32: ``[out, y_0 .. y_{n_next-1}]`` — the node-side block of one AttentionLayer with to_s computed
     inside (``pack``: 12 matrices, see include/qcnet_hip.h) and, with ``next_wt``, the next layer's LayerNorm + projections
-    applied to the output row (``next_wt`` / ``next_bias`` as for :func:`ln_linear`, 1..3 matrices)."""
-    return list(_op('attn_post_chain')(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, _mode(mode)))
+    applied to the output row (``next_wt`` / ``next_bias`` as for :func:`ln_linear`, 1..3 matrices; ``next_operand_scale``:
+    ``static_operand_scale(layer_norm_bound(next_ln_weight, next_ln_bias))`` or 0 for per-row maxima)."""
+    return list(_op('attn_post_chain')(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias,
+                                       float(next_operand_scale), _mode(mode)))
 
 
-def _attn_post_chain_fake(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, mode):
+def _attn_post_chain_fake(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, next_operand_scale, mode):
     n_next = 0 if next_wt is None else next_wt.numel() // (C * C + 2)
     return [torch.empty_like(agg) for _ in range(1 + n_next)]
 
 
 @_register('attn_post_chain', '(Tensor agg, Tensor x_res, Tensor pack, Tensor? next_wt, Tensor? next_bias, Tensor? next_ln_weight, '
-           'Tensor? next_ln_bias, int mode) -> Tensor[]', _attn_post_chain_fake)
-def _attn_post_chain(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, mode):
+           'Tensor? next_ln_bias, float next_operand_scale, int mode) -> Tensor[]', _attn_post_chain_fake)
+def _attn_post_chain(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_ln_bias, next_operand_scale, mode):
     dev = agg.device
     n = agg.size(0)
     _require(agg, 'agg', torch.float32, dev, (n, C))
@@ -684,8 +740,8 @@ def _attn_post_chain(agg, x_res, pack, next_wt, next_bias, next_ln_weight, next_
     tok = _prof_begin(PROF_GEMM, float(n) * (12 + n_next) * 2.0 * C * C, dev)
     _lib.check(_lib.lib().qcn_attn_post_chain_f32(_ptr(agg), _ptr(x_res), _ptr(pack), n, _ptr(outs[0]), _ptr(next_wt),
                                                   _ptr(next_bias) if n_next else None, _ptr(next_ln_weight) if n_next else None,
-                                                  _ptr(next_ln_bias) if n_next else None, n_next, yp[0], yp[1], yp[2], int(mode),
-                                                  _stream(dev)), 'qcn_attn_post_chain_f32')
+                                                  _ptr(next_ln_bias) if n_next else None, float(next_operand_scale), n_next, yp[0],
+                                                  yp[1], yp[2], int(mode), _stream(dev)), 'qcn_attn_post_chain_f32')
     _prof_end(tok, dev)
     return outs
 

@@ -129,20 +129,17 @@ def test_op_attn_post_chain(mode, n_next, n_rows):
         p[n + '_g'] = 1.0 + mk(128, seed=40 + i)
         p[n + '_b'] = mk(128, seed=50 + i)
     f = lambda t: t.float().to(DEV)
-    mats = [f(p['wg'][:, :128]), f(p['wg'][:, 128:]), f(p['ws']), f(p['wo'])]
-    for hb in range(4):
-        mats += [f(p['w1'][128 * hb:128 * hb + 128]), f(p['w2'][:, 128 * hb:128 * hb + 128])]
-    packed, scales = ops.pack_chain_set(mats, mode=mode)
-    vecs = [p['bg'], p['bo'], p['lp_g'], p['lp_b'], p['lf_g'], p['lf_b'], p['b1'], p['b2'], p['lq_g'], p['lq_b'], p['pre_g'],
-            p['pre_b'], p['bs']]
-    pack = torch.cat([packed.reshape(-1)] + [f(v).reshape(-1) for v in vecs] + [ops.scale_table(scales)]).contiguous()
+    pack = ops.pack_attn_post_chain(f(p['wg']), f(p['bg']), f(p['ws']), f(p['bs']), f(p['wo']), f(p['bo']), f(p['w1']), f(p['b1']),
+                                    f(p['w2']), f(p['b2']), (f(p['lp_g']), f(p['lp_b'])), (f(p['lf_g']), f(p['lf_b'])),
+                                    (f(p['lq_g']), f(p['lq_b'])), (f(p['pre_g']), f(p['pre_b'])), mode=mode)
     agg, x = (_rand(n_rows, 128, seed=60 + i).double() for i in range(2))
     nw = [mk(128, 128, seed=80 + j) for j in range(n_next)]
     nb = mk(max(n_next, 1), 128, seed=90)[:n_next]
     args = [None] * 4
     if n_next:
         args = [ops.pack_chain_matrices([f(w) for w in nw], mode=mode), f(nb), f(p['nx_g']), f(p['nx_b'])]
-    outs = op('attn_post_chain')(f(agg), f(x), pack, *args, mode)
+    nsc = ops.static_operand_scale(ops.layer_norm_bound(p['nx_g'], p['nx_b'])) if n_next == 3 else 0.0   # both operand forms
+    outs = op('attn_post_chain')(f(agg), f(x), pack, *args, nsc, mode)
     assert len(outs) == 1 + n_next
     if mode == ops.MATMUL_BF16:   # every matrix operand rounded to bf16: compare loosely with the fp64 form (exercises the path)
         tol = 3e-2
