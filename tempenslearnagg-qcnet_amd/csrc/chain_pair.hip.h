@@ -205,21 +205,7 @@ __device__ __forceinline__ void run_steps(Staged &P, Load load, Step step)
 // ---- operand construction, four elements at a time -------------------------------------------------------------------
 // Registers 4 q .. 4 q + 3 of v[t] (a "group": features 32 t + 8 q + 4 h ..+3 of the lane's row) are half of operand
 // fragment 2 t + (q >> 1).  `x` is already in the operand's static scale (make_operand_static).
-__device__ __forceinline__ float lo_of(float x, half2v hh, int k)
-{
-    // x - (float)hh[k] in ONE instruction: v_fma_mix_f32 widens the f16 half on the fly (the compiler emits v_cvt_f32_f16 +
-    // v_sub_f32 for the plain expression)
-#ifdef QCN_NO_MIX
-    return x - (float)hh[k];
-#endif
-    float r;
-    if (k == 0)
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
-    else
-        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
-    return r;
-}
-
+// (lo_of: chain_tile.hip.h)
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 // elements 2 p, 2 p + 1 of group (t, q): one packed word of the hi plane and one of the lo plane

@@ -139,6 +139,21 @@ template <> struct Operand<kModeExact> { f32x16 v[4]; };
 template <> struct Operand<kModeSplit> { half8 hi[8], lo[8]; float sc, usc; };
 template <> struct Operand<kModeBf16> { bf16x8 v[8]; };
 
+// x - (float)hh[k] in ONE instruction: v_fma_mix_f32 widens the f16 half on the fly (the compiler emits v_cvt_f32_f16 +
+// v_sub_f32 for the plain expression); exact either way (the difference is representable), so the bits do not change
+__device__ __forceinline__ float lo_of(float x, half2v hh, int k)
+{
+#ifdef QCN_NO_MIX
+    return x - (float)hh[k];
+#endif
+    float r;
+    if (k == 0)
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
+    else
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
+    return r;
+}
+
 __device__ __forceinline__ void make_operand(Operand<kModeExact> &o, const f32x16 (&in)[4])
 {
 #pragma unroll
@@ -167,7 +182,7 @@ __device__ __forceinline__ void make_operand(Operand<kModeSplit> &o, const f32x1
             const int r = 8 * (j & 1) + 2 * p;
             const float x0 = in[j >> 1][r] * o.sc, x1 = in[j >> 1][r + 1] * o.sc;
             const half2v hh = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-            const float r0 = x0 - (float)hh[0], r1 = x1 - (float)hh[1];      // exact in fp32
+            const float r0 = lo_of(x0, hh, 0), r1 = lo_of(x1, hh, 1);        // exact in fp32
             const half2v ll = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
             o.hi[j][2 * p] = hh[0]; o.hi[j][2 * p + 1] = hh[1];
             o.lo[j][2 * p] = ll[0]; o.lo[j][2 * p + 1] = ll[1];
@@ -213,7 +228,7 @@ __device__ __forceinline__ void make_operand_static(Operand<kModeSplit> &o, cons
             const int r = 8 * (j & 1) + 2 * p;
             const float x0 = in[j >> 1][r], x1 = in[j >> 1][r + 1];
             const half2v hh = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-            const float r0 = x0 - (float)hh[0], r1 = x1 - (float)hh[1];      // exact in fp32
+            const float r0 = lo_of(x0, hh, 0), r1 = lo_of(x1, hh, 1);        // exact in fp32
             const half2v ll = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(r0, r1));
             o.hi[j][2 * p] = hh[0]; o.hi[j][2 * p + 1] = hh[1];
             o.lo[j][2 * p] = ll[0]; o.lo[j][2 * p + 1] = ll[1];
