@@ -39,23 +39,28 @@ __device__ __forceinline__ float fourier_angle(float xv, float f, float *p_out)
     return __fmul_rn(p, 6.2831854820251465f);    // 2 * 3.1415927410125732 (pi rounded to fp32), exactly representable
 }
 
-// sin and cos of that fp32 angle: three-term Cody-Waite reduction by 2 pi (fma, so every step is exact up to the final
-// rounding of the remainder) and the revolution-based hardware v_sin_f32 / v_cos_f32.  The multiple k of 2 pi is rint(p)
-// — p is the angle in revolutions up to 1e-7 relative, so the remainder stays within +-(pi + 1e-3) — which takes the
-// rounding of k off the dependency chain p -> angle -> remainder -> sin (one wave per SIMD runs this chain unhidden).
-// Max abs error against the exact sin / cos of the same fp32 angle: 3.7e-7 for |angle| < 6000 (ocml sincosf: 7e-8;
-// scripts/dbg/sincos_acc.hip) at a quarter of its instruction count.
-// Valid for |ang| <= 2^15 (the caller takes the ocml path for a lane's whole input dim otherwise, see fourier_kernel).
+// sin and cos of that fp32 angle on the revolution-based hardware v_sin_f32 / v_cos_f32: rev = ang / (2 pi) - k with
+// 1 / (2 pi) carried as hi + lo (two fmas; the first one is exact up to its final rounding because ang * hi and k cancel to
+// a value below one) and k = rint(p) — p is the angle in revolutions up to 1e-7 relative, so |rev| <= 0.5 + 5e-6 — which
+// keeps the rounding of k off the dependency chain p -> angle -> rev -> sin (one wave per SIMD runs this chain unhidden).
+// Max abs error of rev against the exact value 3.3e-8, i.e. 2.1e-7 in the sine of the same fp32 angle for |angle| < 2^15
+// (the three-term Cody-Waite form in radians it replaces: 3.3e-7 at two instructions more per angle; ocml sincosf: 7e-8,
+// scripts/dbg/sincos_acc.hip).  Valid for |ang| <= 2^15 (the caller takes the ocml path for a lane's whole input dim
+// otherwise, see fourier_kernel).
 __device__ __forceinline__ void fourier_sincos(float xv, float f, float *sn, float *cs)
 {
-    const float inv2pi = 0.15915494309189535f;
     float p;
     const float ang = fourier_angle(xv, f, &p);
     const float k = rintf(p);
-    float r = fmaf(-k, 6.28125f, ang);                       // 2 pi = 6.28125 + 1.9350051879882812e-3 + 3.0199159795e-7
+#ifdef QCN_SINCOS_CW     // the three-term Cody-Waite form (A/B builds)
+    float r = fmaf(-k, 6.28125f, ang);
     r = fmaf(-k, 1.9350051879882812e-3f, r);
     r = fmaf(-k, 3.0199159795074593e-7f, r);
-    const float rev = r * inv2pi;
+    const float rev = r * 0.15915494309189535f;
+#else
+    float rev = fmaf(ang, 0.15915493667125702f, -k);         // 1 / (2 pi) = 0.15915493667125702 + 6.4206382432985265e-09
+    rev = fmaf(ang, 6.4206382432985265e-09f, rev);
+#endif
     *sn = __builtin_amdgcn_sinf(rev);
     *cs = __builtin_amdgcn_cosf(rev);
 }
@@ -84,10 +89,11 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
 {
     // two matrix buffers + the per-feature vectors, in ONE __shared__ array (see attn_post_kernel)
     constexpr int kVecBlock = IN * kDimVecs + kOutVecs + kScales;
-    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + kVecBlock / 4 + WAVES * 128];
+    constexpr int kTailBias = 3 * kC;                // biases of the tail's layers, staged behind the pack's vectors
+    __shared__ __attribute__((aligned(16))) f32x4 wlds[2 * kMatVec4 + (kVecBlock + kTailBias) / 4 + WAVES * 128];
     f32x4 *const buf0 = wlds, *const buf1 = wlds + kMatVec4;
     float *const svec = reinterpret_cast<float *>(wlds + 2 * kMatVec4);
-    f32x4 *const xpose = wlds + 2 * kMatVec4 + kVecBlock / 4 + (threadIdx.x >> 6) * 128;   // store_tile2: coalesced row stores
+    f32x4 *const xpose = wlds + 2 * kMatVec4 + (kVecBlock + kTailBias) / 4 + (threadIdx.x >> 6) * 128;   // store_tile2: coalesced row stores
     const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int64_t row = (int64_t)blockIdx.x * (WAVES * kRowsPerWave) + wave * kRowsPerWave + (lane & 31);
@@ -114,6 +120,8 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     const Skew skew = make_skew<WAVES>(skew_mode, wave);
     stage_matrix<WAVES, MODE>(mats, buf0, wave, lane);
     stage_vectors<WAVES>(pack + (size_t)(2 * IN + 1) * kMatFloats, svec, kVecBlock, tid);
+    if (tail.n_out > 0)
+        for (int i = tid; i < tail.n_out * kC; i += 64 * WAVES) svec[kVecBlock + i] = tail.bias != nullptr ? tail.bias[i] : 0.f;
     __syncthreads();
     skew_begin(skew);
 
@@ -217,13 +225,13 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     const float *tsc = tail.wt + (size_t)tail.n_out * kMatFloats;
 #pragma unroll 1
     for (int j = 0; j < tail.n_out; ++j) {
+        // (split mode: the bias joins in the one fma that brings the accumulators back from the operands' scale)
         f32x16 acc[4];
-        if (tail.bias != nullptr) load_feature_vec(acc, tail.bias + j * kC, h);
-        else fill_zero(acc);
         sync_for_stage();
-        gemm<WAVES>(acc, op, wlds + ((j + first_buf) & 1) * kMatVec4, tsc + 2 * j, lane,
-                    j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr,
-                    wlds + ((j + first_buf + 1) & 1) * kMatVec4, wave);
+        gemm_add<WAVES, MODE>(acc, op, wlds + ((j + first_buf) & 1) * kMatVec4, tsc + 2 * j, lane,
+                              BiasTerm{svec + kVecBlock + j * kC, h},
+                              j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr,
+                              wlds + ((j + first_buf + 1) & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
         if (tail.gru_steps > 0) {
             if (gru_tile >= 0) {            // (uniform per wave) the padding sequences of the last block are written too
