@@ -106,6 +106,17 @@ constexpr int kHRow = kC + 8;               // halfs per LDS row
 constexpr int kGruPackFloats = 3 * 4 * 8 * 2 * 64 * 4;   // [gate][wave][k16-step][plane][lane] x 16 B
 constexpr int kGruScaleFloats = 8;          // {s_r, 1/s_r, s_z, 1/s_z, s_n, 1/s_n, s_h, 1/s_h}
 
+// x - (float)hh[k] in one v_fma_mix_f32 (exact either way; v_cvt_f32_f16 + v_sub_f32 otherwise: see chain_tile.hip.h)
+__device__ __forceinline__ float lo_of(float x, half2v hh, int k)
+{
+    float r;
+    if (k == 0)
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
+    else
+        asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(hh), "v"(x));
+    return r;
+}
+
 // Gate non-linearities on the hardware exp2 / rcp (v_exp_f32, v_rcp_f32: ~1 ulp each): sigmoid(x) = 1 / (1 + 2^(-x log2 e)),
 // tanh(x) = 1 - 2 / (1 + 2^(2 x log2 e)); absolute error ~1e-7 on values in [-1, 1], a fraction of the instructions of
 // the ocml expf / tanhf calls that dominated the step's dependent chain.
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(256) void gru_split_kernel(const float *__restrict_
             for (int i = 0; i < 4; i += 2) {
                 const float x0 = hreg[4 * q + i] * s_hid, x1 = hreg[4 * q + i + 1] * s_hid;
                 const half2v a = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0, x1));
-                const half2v b = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(x0 - (float)a[0], x1 - (float)a[1]));
+                const half2v b = __builtin_bit_cast(half2v, __builtin_amdgcn_cvt_pkrtz(lo_of(x0, a, 0), lo_of(x1, a, 1)));
                 hi4[i] = a[0]; hi4[i + 1] = a[1]; lo4[i] = b[0]; lo4[i + 1] = b[1];
             }
             const int f0 = 32 * wave + 8 * q + 4 * hh;
