@@ -385,8 +385,10 @@ def test_attention_layer_vs_oracle_in_both_matmul_modes(mode, restore_matmul_mod
 def test_trajectory_gru_blocked_layout_equals_row_major(n_seq, in_dim, folded, mode, restore_matmul_mode):
     """ops.trajectory_gru (qcn_fourier_gru_input_f32 + qcn_gru_blocked_f32: the GRU's input halves in the recurrence's own
     blocked layout, a tile = one step of 32 sequences) against ops.fourier_linear + ops.gru_recurrence (row-major input halves)
-    — the same arithmetic on the same values, so BIT-IDENTICAL; ragged sequence counts (padding of the last block), one
-    sequence, both tail forms, split and bf16 modes."""
+    — the same input halves bit for bit (the two chain kernels share their arithmetic); the blocked recurrence is the two-group
+    kernel, whose gates fold log2(e) into their constants and carry the state pre-scaled, so the 60-step results agree to a
+    few ulps of the state's range, not bit for bit: |diff| <= 2e-6 on values in [-1, 1].  Ragged sequence counts (padding of
+    the last block, an odd number of blocks), one sequence, both tail forms, split and bf16 modes."""
     from tempenslearnagg_qcnet_amd.layers import FourierEmbedding
     ops.set_matmul_mode(mode)
     torch.manual_seed(5)
@@ -416,7 +418,7 @@ def test_trajectory_gru_blocked_layout_equals_row_major(n_seq, in_dim, folded, m
         want = ops.gru_recurrence(gi[0], gi[1], gi[2], n_steps, whh, b_hh, h0, mode=mode)
         got = ops.trajectory_gru(x, in_dim, n_steps, emb.packed_weights(), wt, bs, folded, whh, b_hh, h0, mode=mode)
     assert got.shape == (n_seq, 128) and bool(torch.isfinite(got).all())
-    assert torch.equal(got, want)
+    assert float((got - want).abs().max()) <= 2e-6
 
 
 @pytest.mark.parametrize('mode', [1, 0])

@@ -215,8 +215,10 @@ def test_fast_path_switches_do_not_change_predictions():
 def test_fallback_branches_give_the_default_path_s_predictions():
     """The switches behind the default path (they are read at import time, so their fallback branches never ran
     under pytest): TemporalAggregate's proposal half behind the ten-frame pass instead of beside it, the per-edge projection
-    tables off (recomputation), the heavy Fourier launches left on the preparation stream, the GRU input halves row-major —
-    each only moves work or re-does the same arithmetic: BIT-IDENTICAL predictions.  The unchained node side
+    tables off (recomputation), the heavy Fourier launches left on the preparation stream — each only moves work or re-does
+    the same arithmetic: BIT-IDENTICAL predictions.  The GRU input halves row-major select the one-group recurrence kernel,
+    whose gates round in another order than the two-group kernel of the blocked layout (a few ulps of the state): 1e-5.  The
+    unchained node side
     (qcn_ln_linear_f32 + qcn_attn_post_f32 instead of qcn_attn_post_chain_f32) adds its biases in another order: 1e-5."""
     from tempenslearnagg_qcnet_amd.layers import attention_layer
     from tempenslearnagg_qcnet_amd.modules import qcnet_decoder
@@ -237,7 +239,10 @@ def test_fallback_branches_give_the_default_path_s_predictions():
             finally:
                 setattr(obj, name, old)
             for k in keys:
-                assert torch.equal(got[k], want[k]), (name, k)
+                if name == 'BLOCKED_GRU_INPUT':
+                    assert rel_err(got[k], want[k]) < 1e-5, (name, k)
+                else:
+                    assert torch.equal(got[k], want[k]), (name, k)
         try:
             attention_layer.CHAIN_NODE_SIDE = False
             got = model.predict(batch)
