@@ -3,7 +3,7 @@ spans the last two bench steps (delimited by the gru_split_kernel launches, two 
 import csv, sys
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort()
-gru = [s for s, e, n in rows if 'gru_split' in n]
+gru = [s for s, e, n in rows if 'gru_split' in n or 'gru_pair' in n]
 t0, t1 = gru[-5], gru[-1]
 win = [(s, e, n) for s, e, n in rows if t0 <= s < t1]
 busy = sum(e - s for s, e, n in win)

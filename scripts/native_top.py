@@ -4,7 +4,7 @@ import csv, sys, glob, collections, re
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'], r.get('Queue_Id', '0'), r['Grid_Size_X']) for r in csv.DictReader(open(f))]
 rows.sort()
-gru = [s for s, e, n, q, g in rows if 'gru_split' in n]
+gru = [s for s, e, n, q, g in rows if 'gru_split' in n or 'gru_pair' in n]
 t0, t1 = gru[-5], gru[-1]
 tot = collections.Counter(); cnt = collections.Counter()
 for s, e, n, q, g in rows:

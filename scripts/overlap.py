@@ -12,7 +12,7 @@ def fam(n):
         if k in n:
             return k
     return 'other'
-gru = [s for s, e, n, q in rows if 'gru_split' in n]
+gru = [s for s, e, n, q in rows if 'gru_split' in n or 'gru_pair' in n]
 t0, t1 = gru[-5], gru[-1]
 win = [(s, e, fam(n), q) for s, e, n, q in rows if t0 <= s < t1]
 tot = collections.Counter(); cnt = collections.Counter(); co = collections.defaultdict(collections.Counter)

@@ -3,7 +3,7 @@ import csv, sys, glob, collections
 f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
 rows = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in csv.DictReader(open(f))]
 rows.sort()
-gru = [s for s, e, n in rows if 'gru_split' in n]
+gru = [s for s, e, n in rows if 'gru_split' in n or 'gru_pair' in n]
 t0, t1 = gru[-5], gru[-1]
 win = [(s, e, n) for s, e, n in rows if t0 <= s < t1]
 fam = collections.Counter(); cnt = collections.Counter()

@@ -5,7 +5,7 @@ import collections, csv, glob, json, sys
 
 f = (glob.glob(sys.argv[1] + '/*/*counter_collection.csv') + glob.glob(sys.argv[1] + '/*counter_collection.csv'))[0]
 FAMILIES = ('attn_modes_kernel', 'attn_kv_kernel', 'attn_fused_kernel', 'attn_fwd_kernel', 'fourier_pair_kernel', 'fourier_kernel', 'attn_post_kernel', 'ln_linear_kernel',
-            'gru_split_kernel', 'mlp_heads_kernel')
+            'gru_split_kernel', 'gru_pair_kernel', 'mlp_heads_kernel')
 rows = collections.defaultdict(lambda: collections.defaultdict(list))       # family -> counter -> per-dispatch values
 for r in csv.DictReader(open(f)):
     fam = next((k for k in FAMILIES if k in r['Kernel_Name']), None)
