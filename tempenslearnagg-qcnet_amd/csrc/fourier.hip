@@ -223,16 +223,20 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     // buffer (j + 1) & 1 behind to_out's matrix, in buffer j & 1 when that GEMM is folded away
     const int first_buf = tail.fold ? 0 : 1;
     const float *tsc = tail.wt + (size_t)tail.n_out * kMatFloats;
-#pragma unroll 1
-    for (int j = 0; j < tail.n_out; ++j) {
+    // The stores of layer j are issued AFTER the stage barrier of layer j + 1: that barrier begins with vmcnt(0) (the LDS-DMA of
+    // the layer's matrix must have landed), and vmcnt counts stores too — issued in front of it, every wave of the block sat
+    // out the round trip of its sixteen stores to L2 three times per tile.  Behind it they have the whole GEMM to drain: 1 % of
+    // the launch at 5.76 M rows (an ablation without the stores says they cost 1.0 of its 3.9 ms: 8.8 GB, mostly HBM time that
+    // does not hide under the GEMMs) (the finished accumulators wait in a second register set).
+    auto tail_gemm = [&](int j, f32x16 (&acc)[4]) {
         // (split mode: the bias joins in the one fma that brings the accumulators back from the operands' scale)
-        f32x16 acc[4];
-        sync_for_stage();
         gemm_add<WAVES, MODE>(acc, op, wlds + ((j + first_buf) & 1) * kMatVec4, tsc + 2 * j, lane,
                               BiasTerm{svec + kVecBlock + j * kC, h},
                               j + 1 < tail.n_out ? tail.wt + (size_t)(j + 1) * kMatFloats : nullptr,
                               wlds + ((j + first_buf + 1) & 1) * kMatVec4, wave);
         skew_after_gemm(skew);
+    };
+    auto tail_store = [&](int j, f32x16 (&acc)[4]) {
         if (tail.gru_steps > 0) {
             if (gru_tile >= 0) {            // (uniform per wave) the padding sequences of the last block are written too
                 float *dst = tail.y[j] + gru_tile * (int64_t)(kRowsPerWave * kC) + lane * 4;
@@ -243,13 +247,25 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
                         f32x4 v;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) v[i] = acc[t][4 * q + i];
-                        *reinterpret_cast<f32x4 *>(dst + (4 * t + q) * 256) = v;
+                        // (non-temporal: 8.8 GB per launch at cfg3 that nothing reads before the recurrence streams it back)
+                        __builtin_nontemporal_store(v, reinterpret_cast<f32x4 *>(dst + (4 * t + q) * 256));
                     }
             }
         } else {
             store_tile2(acc, tail.y[j], row0, n_rows, xpose, lane);
         }
+    };
+    f32x16 acc_prev[4];
+#pragma unroll 1
+    for (int j = 0; j < tail.n_out; ++j) {
+        sync_for_stage();
+        if (j > 0) tail_store(j - 1, acc_prev);
+        f32x16 acc[4];
+        tail_gemm(j, acc);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc_prev[t] = acc[t];
     }
+    tail_store(tail.n_out - 1, acc_prev);
     skew_end(skew);
 }
 
