@@ -249,9 +249,12 @@ def test_op_gru_recurrence():
     assert rel_err(got, want) < 1e-5
 
 
-def test_op_trajectory_gru():
+@pytest.mark.parametrize('n_seq,n_steps', [(70, 9), (5, 1), (33, 2), (64, 3), (161, 60)])
+def test_op_trajectory_gru(n_seq, n_steps):
     """FourierEmbedding -> GRU input matrices -> GRU recurrence as one op (modules/qcnet_decoder.py:255-257), against
-    torch.nn.GRU fed with the fp64 embedding."""
+    torch.nn.GRU fed with the fp64 embedding.  The recurrence is the two-group kernel (two blocks of 32 sequences per
+    workgroup, half a step apart): one and two steps exercise its prologue / epilogue phases alone, 5 / 33 / 161 sequences the
+    workgroup whose second group repeats the last block, 64 the exact fit."""
     mode = ops.MATMUL_SPLIT_F16
     torch.manual_seed(120)
     m = FourierEmbedding(input_dim=2, hidden_dim=128, num_freq_bands=64).eval().to(DEV)
@@ -259,7 +262,6 @@ def test_op_trajectory_gru():
     with torch.no_grad():
         for prm in gru.parameters():
             prm.copy_(torch.randn_like(prm) * 0.12)
-    n_seq, n_steps = 70, 9
     x = _rand(n_seq * n_steps, 2, seed=121, scale=5.0).to(DEV)
     h0 = (_rand(128, seed=122) * 0.3).to(DEV)
     with torch.no_grad():
