@@ -216,6 +216,15 @@ struct Slot {
     unsigned char r[kTile * kRowBytes], k[kTile * kRowBytes], v[kTile * kRowBytes];
 };
 
+// Cache policy of everything that streams through once per launch — the positional rows (LDS-DMA aux bit 1 = nt on gfx950),
+// the per-edge tables written by the STORE launch and read by attn_kv_kernel: non-temporal, so that 0.5-2 GB per launch do
+// not push the gathered k / v rows out of L2 / MALL.  Same box, pl2m relation of cfg3 (2.03 M edges): table attention 478 ->
+// 433 us (4.36 -> 4.80 TB/s of tables), recomputing launch 858 -> 839 us, STORE launch 936 -> 923 us.  QCN_NO_NT: A/B builds.
+#ifdef QCN_NO_NT
+#define QCN_RS_AUX 0
+#else
+#define QCN_RS_AUX 2
+#endif
 template <bool BF16>
 __device__ __forceinline__ void issue_tile_dma(const ModesArgs &a, const TileIdx &x, Slot *slot, int wave, int lane)
 {
@@ -234,13 +243,13 @@ __device__ __forceinline__ void issue_tile_dma(const ModesArgs &a, const TileIdx
         __builtin_amdgcn_sched_barrier(0);
         if (lane < 32)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sr,
-                                             (__attribute__((address_space(3))) void *)(slot->r + wave * 512), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void *)(slot->r + wave * 512), 16, 0, QCN_RS_AUX);
     } else {
         const uint32_t cr = (uint32_t)(((pc & 15) ^ e) | (pc & 16));     // rhat: logical chunk (hi half 0..15, lo half 16..31)
         const char *sr = reinterpret_cast<const char *>(a.rs) + ((uint32_t)x.rid * 512u + cr * 16u);
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sr,
-                                         (__attribute__((address_space(3))) void *)(slot->r + wave * 1024), 16, 0, 0);
+                                         (__attribute__((address_space(3))) void *)(slot->r + wave * 1024), 16, 0, QCN_RS_AUX);
     }
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)sk,
                                      (__attribute__((address_space(3))) void *)(slot->k + wave * 1024), 16, 0, 0);
@@ -522,9 +531,15 @@ __global__ __launch_bounds__(64 * kHeads) void attn_modes_kernel(ModesArgs a)
             // masked off; the tail of the row's last group (its padding slots) receives the last edge's values.
             if (t.row >= 0) {         // (uniform; without a next tile the iteration returns before its wait)
                 const int last = t.end - 1 - t.j0;
+#ifndef QCN_NO_NT
+                __builtin_nontemporal_store(kk_t, reinterpret_cast<f32x4 *>(kk_plane + kk_slot_off((uint32_t)(t.s0 + min(i, last)), wave, g)));
+                if (4 * g <= last)
+                    __builtin_nontemporal_store(vv_t, reinterpret_cast<f32x4 *>(vv_plane + vv_group_off((uint32_t)((t.s0 >> 2) + g), wave, i)));
+#else
                 *reinterpret_cast<f32x4 *>(kk_plane + kk_slot_off((uint32_t)(t.s0 + min(i, last)), wave, g)) = kk_t;
                 if (4 * g <= last)
                     *reinterpret_cast<f32x4 *>(vv_plane + vv_group_off((uint32_t)((t.s0 >> 2) + g), wave, i)) = vv_t;
+#endif
             }
         }
     };
@@ -720,8 +735,13 @@ __global__ __launch_bounds__(64 * kHeads, QCN_KV_MIN_WAVES) void attn_kv_kernel(
         const Tile t = t_in.row >= 0 ? t_in : tl[0];             // past the last tile: a harmless duplicate
         const int last = t.end - 1 - t.j0;
         // positions / groups past the row's end re-read its last edge / last group (finite values; their weights are 0)
+#ifndef QCN_NO_NT
+        kkr[S] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(kk_plane + kk_slot_off((uint32_t)(t.s0 + min(i, last)), wave, g)));
+        vvr[S] = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(vv_plane + vv_group_off((uint32_t)((t.s0 >> 2) + min(g, last >> 2)), wave, i)));
+#else
         kkr[S] = ld_off<f32x4>(kk_plane, kk_slot_off((uint32_t)(t.s0 + min(i, last)), wave, g));
         vvr[S] = ld_off<f32x4>(vv_plane, vv_group_off((uint32_t)((t.s0 >> 2) + min(g, last >> 2)), wave, i));
+#endif
         qr[S] = load_q(a, na, t.row);
     };
     request(std::integral_constant<int, 0>{}, tl[0]);
