@@ -397,7 +397,10 @@ int qcn_gru_f32(const float *gi_r, const float *gi_z, const float *gi_n, const f
  *     qcn_gru_blocked_rows(n_seq, n_steps) * 128 floats (the last sequence block is padded to 32; padding is written);
  *   qcn_gru_blocked_f32 = qcn_gru_f32 in the split-f16 arithmetic (whh = its split pack) reading that layout: the twelve
  *     loads of a step are contiguous 1 KiB pieces per wave (row-major gi: 32-byte pieces of 32 rows each), and the producer
- *     stores straight from its accumulator registers.  Same values, bit for bit, as the row-major pair of calls. */
+ *     stores straight from its accumulator registers.  The input halves are the same bits as the row-major call's; the
+ *     recurrence itself is the two-group kernel (two blocks of 32 sequences per workgroup half a step apart, input halves by
+ *     LDS-DMA, 132 KiB of LDS per workgroup; csrc/gru.hip), whose gates round in another order than qcn_gru_f32's: the
+ *     final states agree to a few 1e-7 on values in [-1, 1], not bit for bit.  Deterministic run to run. */
 int64_t qcn_gru_blocked_rows(int64_t n_seq, int n_steps);
 int qcn_fourier_gru_input_f32(const float *x, int input_dim, const float *pack, int64_t n_seq, int n_steps,
                               const float *wt, const float *bias, int folded, float *gi_r, float *gi_z, float *gi_n,
