@@ -92,7 +92,9 @@ __device__ __forceinline__ void slot_pattern()
 __device__ unsigned long long g_slot_stamps[kPairWaves][32];
 #endif
 
-template <typename Load, typename Step>
+// ZERO: the accumulators start at zero — the first MFMA of each takes the constant instead of 64 registers zeroed beforehand
+// (32 v_mov_b64 per GEMM and tile in kernels whose vector issue is the bound)
+template <bool ZERO = false, typename Load, typename Step>
 __device__ __forceinline__ void gemm_bt(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w, int lane,
                                         const float *__restrict__ next, f32x4 *next_dst, int wave, int half, Staged &P, Load load,
                                         Step step, int stamp = 0)
@@ -101,6 +103,9 @@ __device__ __forceinline__ void gemm_bt(f32x16 (&acc)[4], const Operand<kModeSpl
     // weight fragments are requested TWO slots ahead: a slot that carries little vector work is three MFMAs long, less than an
     // LDS round trip at this occupancy
     f32x4 nh = w[lane], nl = w[64 + lane], nh2 = w[2 * 64 + lane], nl2 = w[3 * 64 + lane];
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) {            // g = 4 j + t
         const int j = g >> 2, t = g & 3;
@@ -108,7 +113,7 @@ __device__ __forceinline__ void gemm_bt(f32x16 (&acc)[4], const Operand<kModeSpl
         nh = nh2;
         nl = nl2;
 #ifndef QCN_EXP_NO_MFMA
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], ZERO && j == 0 ? zero : acc[t], 0, 0, 0);
 #else
         acc[t][g & 15] += (float)ah[0] * (float)in.hi[j][0] + (float)al[1] * (float)in.lo[j][1];
 #endif
@@ -139,12 +144,13 @@ __device__ __forceinline__ void gemm_bt(f32x16 (&acc)[4], const Operand<kModeSpl
     }
 }
 
-template <typename Load, typename Step>
+template <bool ZERO = false, typename Load, typename Step>
 __device__ __forceinline__ void gemm_bt(f32x16 (&acc)[4], const Operand<kModeBf16> &in, const f32x4 *w, int lane,
                                         const float *__restrict__ next, f32x4 *next_dst, int wave, int half, Staged &P, Load load,
                                         Step step, int = 0)
 {
     using PP = PairPieces<kModeBf16>;
+    if constexpr (ZERO) fill_zero(acc);
     f32x4 cur_w = w[lane];
 #pragma unroll
     for (int g = 0; g < 32; ++g) {            // g = 4 j + t
@@ -161,12 +167,13 @@ __device__ __forceinline__ void gemm_bt(f32x16 (&acc)[4], const Operand<kModeBf1
     }
 }
 
-template <typename Load, typename Step>
+template <bool ZERO = false, typename Load, typename Step>
 __device__ __forceinline__ void gemm_bt(f32x16 (&acc)[4], const Operand<kModeExact> &in, const f32x4 *w, int lane,
                                         const float *__restrict__ next, f32x4 *next_dst, int wave, int half, Staged &P, Load load,
                                         Step step, int = 0)
 {
     using PP = PairPieces<kModeExact>;
+    if constexpr (ZERO) fill_zero(acc);
     f32x4 nxt = w[lane];
 #pragma unroll
     for (int s = 0; s < 64; ++s) {

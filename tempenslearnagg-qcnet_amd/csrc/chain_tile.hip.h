@@ -278,7 +278,8 @@ __device__ __forceinline__ void gemm(f32x16 (&acc)[4], const Operand<kModeExact>
 // The accumulators are moved to the operands' scale and back by two exact power-of-two multiplies.
 // SCALE = false: the accumulators are taken and left in the operands' scale (gemm_add below starts them at zero and folds the
 // way back into the fma that adds the bias).
-template <int WAVES, bool SCALE>
+// ZERO: the accumulators start at zero — the first MFMA of each takes the constant, nothing is zeroed beforehand.
+template <int WAVES, bool SCALE, bool ZERO = false>
 __device__ __forceinline__ void gemm_split_core(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w,
                                                 const float *__restrict__ mscale, int lane, const float *__restrict__ next,
                                                 f32x4 *next_dst, int wave)
@@ -292,6 +293,9 @@ __device__ __forceinline__ void gemm_split_core(f32x16 (&acc)[4], const Operand<
         for (int t = 0; t < 4; ++t) acc[t] *= S;
     }
     f32x4 nh = w[lane], nl = w[64 + lane];
+    f32x16 zero;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 #ifdef QCN_GEMM_PRIO
     __builtin_amdgcn_s_setprio(QCN_GEMM_PRIO);
 #endif
@@ -300,7 +304,7 @@ __device__ __forceinline__ void gemm_split_core(f32x16 (&acc)[4], const Operand<
         const int j = g >> 2, t = g & 3;
         const half8 ah = __builtin_bit_cast(half8, nh), al = __builtin_bit_cast(half8, nl);
 #ifndef QCN_EXP_NO_MFMA
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], ZERO && j == 0 ? zero : acc[t], 0, 0, 0);
 #else
         acc[t][g & 15] += (float)ah[0] * (float)in.hi[j][0] + (float)al[1] * (float)in.lo[j][1];
 #endif
@@ -388,11 +392,7 @@ __device__ __forceinline__ void gemm_add(f32x16 (&acc)[4], const Operand<MODE> &
                                          const float *__restrict__ next = nullptr, f32x4 *next_dst = nullptr, int wave = 0)
 {
     if constexpr (MODE == kModeSplit) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-        gemm_split_core<WAVES, false>(acc, in, w, mscale, lane, next, next_dst, wave);
+        gemm_split_core<WAVES, false, true>(acc, in, w, mscale, lane, next, next_dst, wave);
         const float U = in.usc * mscale[1];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -418,12 +418,21 @@ __device__ __forceinline__ void gemm_add(f32x16 (&acc)[4], const Operand<MODE> &
 // acc += W in with the accumulators LEFT in the operands' scale (split mode; the other modes have no scale): a sum over
 // several GEMMs whose (operand scale x matrix scale) products the host made equal needs no vector-ALU work between them —
 // the caller applies `acc * U + bias` once at the end.
-template <int WAVES, int MODE>
+template <int WAVES, int MODE, bool ZERO = false>
 __device__ __forceinline__ void gemm_raw(f32x16 (&acc)[4], const Operand<MODE> &in, const f32x4 *w, int lane,
                                          const float *__restrict__ next = nullptr, f32x4 *next_dst = nullptr, int wave = 0)
 {
-    if constexpr (MODE == kModeSplit) gemm_split_core<WAVES, false>(acc, in, w, nullptr, lane, next, next_dst, wave);
-    else gemm<WAVES>(acc, in, w, nullptr, lane, next, next_dst, wave);
+    if constexpr (MODE == kModeSplit) {
+        gemm_split_core<WAVES, false, ZERO>(acc, in, w, nullptr, lane, next, next_dst, wave);
+    } else {
+        if constexpr (ZERO) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        }
+        gemm<WAVES>(acc, in, w, nullptr, lane, next, next_dst, wave);
+    }
 }
 
 // acc = acc * u + add(t, q): the way back from the operands' scale fused with the bias / rank-1 term (one fma per element)

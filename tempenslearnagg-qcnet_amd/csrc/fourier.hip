@@ -171,9 +171,8 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
         // the one fma that also brings the accumulators back from the operands' scale
         make_operand_static(op, ft, 1.0f, 1.0f);
         f32x16 acc_h[4];
-        fill_zero(acc_h);
         sync_for_stage();
-        gemm_raw<WAVES, MODE>(acc_h, op, buf0, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
+        gemm_raw<WAVES, MODE, true>(acc_h, op, buf0, lane, mats + (size_t)(2 * d + 1) * kMatFloats, buf1, wave);
         skew_after_gemm(skew);
         scale_add(acc_h, msc[2 * d], [&](int t, int q) {
             const f32x4 b1 = *reinterpret_cast<const f32x4 *>(dv + kVB1 + 32 * t + 8 * q + 4 * h);
@@ -204,9 +203,8 @@ __global__ __launch_bounds__(64 * WAVES) void fourier_kernel(const float *__rest
     const int64_t row0 = row - (lane & 31);
     if (!tail.fold) {
         f32x16 acc_o[4];
-        fill_zero(acc_o);
         sync_for_stage();
-        gemm_raw<WAVES, MODE>(acc_o, op, buf0, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
+        gemm_raw<WAVES, MODE, true>(acc_o, op, buf0, lane, tail.n_out > 0 ? tail.wt : nullptr, buf1, wave);
         skew_after_gemm(skew);
         scale_add(acc_o, msc[2 * IN], BiasTerm{out_vec + kVOutB, h});
         if (normalize_out) layer_norm<false, false>(acc_o, nullptr, nullptr, h, eps);

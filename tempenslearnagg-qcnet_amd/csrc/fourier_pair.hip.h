@@ -319,16 +319,14 @@ __global__ __launch_bounds__(64 * kPairWaves) void fourier_pair_kernel(const flo
         asm volatile("" : "+v"(dbase));
         auto load_e1 = [&](int g) AI { e1_load(dbase, g); };
         // W1_d is in buffer 0; W2_d goes to buffer 1
-        fill_zero(A.hh);
         load_feat_b(0);
-        gemm_bt(A.hh, A.op, buf0, lane, w2, buf1, wave, 0,
+        gemm_bt<true>(A.hh, A.op, buf0, lane, w2, buf1, wave, 0,
                 QCN_PIPE(load_feat_b, [&](int g, const Staged &cur) AI { feat_step(B, xb, g, cur); }), QCN_SLOT_STAMP_SEL(d == 1, 2));
         feat_finish(B);
         PST()
         feat_cold(B, d, xb);
-        fill_zero(B.hh);
         load_e1(0);
-        gemm_bt(B.hh, B.op, buf0, lane, w2, buf1, wave, 1,
+        gemm_bt<true>(B.hh, B.op, buf0, lane, w2, buf1, wave, 1,
                 QCN_PIPE(load_e1, [&](int g, const Staged &cur) AI { e1_step(A, xa, u1, g, cur); }), QCN_SLOT_STAMP_SEL(d == 1, 1));
         PST()
         PST() sync_for_stage(); PST()
@@ -353,13 +351,11 @@ __global__ __launch_bounds__(64 * kPairWaves) void fourier_pair_kernel(const flo
         PST() sync_for_stage(); PST()
     }
     if (!TAIL) {
-        fill_zero(A.hh);
         eo_load(0);
-        gemm_bt(A.hh, A.op, buf0, lane, pack, buf1, wave, 0, QCN_PIPE(eo_load, [&](int g, const Staged &cur) AI { eo_step(B, g, cur); }));
+        gemm_bt<true>(A.hh, A.op, buf0, lane, pack, buf1, wave, 0, QCN_PIPE(eo_load, [&](int g, const Staged &cur) AI { eo_step(B, g, cur); }));
         PST()
-        fill_zero(B.hh);
         ef_load(0);
-        gemm_bt(B.hh, B.op, buf0, lane, pack, buf1, wave, 1, QCN_PIPE(ef_load, [&](int g, const Staged &cur) AI { ef_step(A, g, cur); }));
+        gemm_bt<true>(B.hh, B.op, buf0, lane, pack, buf1, wave, 1, QCN_PIPE(ef_load, [&](int g, const Staged &cur) AI { ef_step(A, g, cur); }));
         PST()
         ef_load(0);
         run_steps(QCN_PIPE(ef_load, [&](int g, const Staged &cur) AI { ef_step(B, g, cur); }));
@@ -368,13 +364,11 @@ __global__ __launch_bounds__(64 * kPairWaves) void fourier_pair_kernel(const flo
         const float *t1 = tail.n_out > 1 ? tail.wt + kMatFloats : pack;   // (no next matrix: any source, idle buffer)
         const float ut0 = tail_u(0);
         auto load_t0 = [&](int g) AI { et_load(0, g); };
-        fill_zero(A.hh);
         eo_load(0);
-        gemm_bt(A.hh, A.op, buf0, lane, t1, buf1, wave, 0, QCN_PIPE(eo_load, [&](int g, const Staged &cur) AI { eo_step(B, g, cur); }));
+        gemm_bt<true>(A.hh, A.op, buf0, lane, t1, buf1, wave, 0, QCN_PIPE(eo_load, [&](int g, const Staged &cur) AI { eo_step(B, g, cur); }));
         PST()
-        fill_zero(B.hh);
         load_t0(0);
-        gemm_bt(B.hh, B.op, buf0, lane, t1, buf1, wave, 1, QCN_PIPE(load_t0, [&](int g, const Staged &cur) AI { et_step(A, 0, ut0, g, cur); }));
+        gemm_bt<true>(B.hh, B.op, buf0, lane, t1, buf1, wave, 1, QCN_PIPE(load_t0, [&](int g, const Staged &cur) AI { et_step(A, 0, ut0, g, cur); }));
         PST()
 #pragma unroll 1
         for (int j = 1; j < tail.n_out; ++j) {
@@ -385,12 +379,10 @@ __global__ __launch_bounds__(64 * kPairWaves) void fourier_pair_kernel(const flo
             auto load_prev = [&](int g) AI { et_load(j - 1, g); };
             auto load_cur = [&](int g) AI { et_load(j, g); };
             // (tile B's previous result is still being stored while tile A's GEMM runs: A.hh and B.hh are distinct)
-            fill_zero(A.hh);
             load_prev(0);
-            gemm_bt(A.hh, A.op, bj, lane, tn, bn, wave, 0, QCN_PIPE(load_prev, [&](int g, const Staged &cur) AI { et_step(B, j - 1, up, g, cur); }));
-            fill_zero(B.hh);
+            gemm_bt<true>(A.hh, A.op, bj, lane, tn, bn, wave, 0, QCN_PIPE(load_prev, [&](int g, const Staged &cur) AI { et_step(B, j - 1, up, g, cur); }));
             load_cur(0);
-            gemm_bt(B.hh, B.op, bj, lane, tn, bn, wave, 1, QCN_PIPE(load_cur, [&](int g, const Staged &cur) AI { et_step(A, j, uj, g, cur); }));
+            gemm_bt<true>(B.hh, B.op, bj, lane, tn, bn, wave, 1, QCN_PIPE(load_cur, [&](int g, const Staged &cur) AI { et_step(A, j, uj, g, cur); }));
         }
         const int jl = tail.n_out - 1;
         const float ul = tail_u(jl);

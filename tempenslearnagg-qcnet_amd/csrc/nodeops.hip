@@ -188,7 +188,7 @@ __device__ __forceinline__ void hid_step(f32x16 (&a)[4], float U, Operand<kModeS
 // acc += W in with the accumulators left in the operands' scale (gemm_raw), `load(g + 1)` and `step(g, b0, b1)` issued in
 // slot g = 0..31 (chain_pair.hip.h's slot layout: first MFMA, the fragment reads two slots ahead, the LDS-DMA pieces of the
 // next matrix and the step's LDS reads in one scheduling region; the step's vector work around the other two MFMAs).
-template <int WAVES, typename Load, typename Step>
+template <int WAVES, bool ZERO = false, typename Load, typename Step>
 __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[4], const Operand<kModeSplit> &in, const f32x4 *w, int lane,
                                            const float *__restrict__ next, f32x4 *next_dst, int wave, HidSteps &S, Load load,
                                            Step step)
@@ -197,13 +197,16 @@ __device__ __forceinline__ void gemm_steps(f32x16 (&acc)[4], const Operand<kMode
     constexpr int kPerSlot = kPieces > 32 ? kPieces / 32 : 1;
     constexpr int kEvery = kPieces >= 32 ? 1 : 32 / kPieces;
     f32x4 nh = w[lane], nl = w[64 + lane], nh2 = w[2 * 64 + lane], nl2 = w[3 * 64 + lane];
+    f32x16 zero;   // (ZERO: the accumulators start at zero, chain_tile.hip.h gemm_split_core)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 #pragma unroll
     for (int g = 0; g < 32; ++g) {            // g = 4 j + t
         const int j = g >> 2, t = g & 3;
         const half8 ah = __builtin_bit_cast(half8, nh), al = __builtin_bit_cast(half8, nl);
         nh = nh2;
         nl = nl2;
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, in.hi[j], ZERO && j == 0 ? zero : acc[t], 0, 0, 0);
         if (g + 2 < 32) { nh2 = w[(2 * (g + 2)) * 64 + lane]; nl2 = w[(2 * (g + 2) + 1) * 64 + lane]; }
         if (g % kEvery == 0) {
 #pragma unroll
@@ -357,10 +360,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
         auto g1_with_e = [&](f32x16 (&an)[4], f32x16 (&ap)[4], int hb, f32x4 *wb, const float *nx, f32x4 *nb) {
             const float *bias = vec + kVB1 + (hb - 1) * kC;
             const float U = U1(hb - 1);
-            fill_zero(an);
             hid_load(S, bias, h, 0);
             PSTAMP(0) sync_for_stage(); PSTAMP(1)
-            gemm_steps<WAVES>(an, op, wb, lane, nx, nb, wave, S, [&](int g) { hid_load(S, bias, h, g); },
+            gemm_steps<WAVES, true>(an, op, wb, lane, nx, nb, wave, S, [&](int g) { hid_load(S, bias, h, g); },
                               [&](int g, const f32x4 c0, const f32x4 c1) { hid_step<kStatic>(ap, U, hid, S, g, c0, c1); });
             PSTAMP(2)
         };
@@ -370,9 +372,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_post_kernel(const float *__re
             else gemm<WAVES>(acc_o, hid, wb, msc + 2 * (4 + kM + 2 * hb), lane, nx, nb, wave);
             PSTAMP(2)
         };
-        fill_zero(a0);
         PSTAMP(0) sync_for_stage(); PSTAMP(1)
-        gemm_raw<WAVES, MODE>(a0, op, bA, lane, W1(1), bB, wave);                     // W1_0
+        gemm_raw<WAVES, MODE, true>(a0, op, bA, lane, W1(1), bB, wave);               // W1_0
         PSTAMP(2)
         g1_with_e(a1, a0, 1, bB, W2(0), bA);                                          // W1_1 + E_0
         g2(0, bA, W1(2), bB);                                                         // W2_0
