@@ -162,6 +162,7 @@ def main() -> None:
     step_ids = [[(s * world + rank) * batch_size + i for i in range(batch_size)] for s in range(n_pool)]
     batches = [make_batch(ids, **cfg['scene']).to(device) for ids in step_ids]
     step_ms = []
+    host_loop = None
     with torch.no_grad(), torch.cuda.stream(main_stream):
         for b in batches:
             b.mark_ready()
@@ -204,6 +205,7 @@ def main() -> None:
                 part = sharding.validation_metric_sums(data, pred)
                 sums = part if sums is None else sums + part
                 marks[s + 1].record(main_stream)
+            host_loop = time.perf_counter() - t0      # the host has enqueued every timed step (it runs ahead of the GPU)
             # the path's only exchange: gather the per-scenario prediction records and the metric sums
             gathered = sharding.gather_records(torch.cat(records), world)
             sums = sharding.reduce_metric_sums(sums, world)
@@ -334,6 +336,7 @@ def main() -> None:
                                                          'a different batch every step, scenario ids disjoint across ranks and steps'),
                        'global_batch': world * batch_size, 'parallelism': 'scenario-sharded x%d' % world,
                        'matmul': MATMUL_NOTE[mode]},
+            'host_enqueue_ms_per_step': None if host_loop is None else host_loop * 1e3 / steps,   # < ms_per_step: the GPU is the bound
             'step_ms': None if not step_ms else {'median': statistics.median(step_ms), 'min': min(step_ms), 'max': max(step_ms), 'all': [round(v, 2) for v in step_ms],
                                                  'note': 'per-step GPU time between events on the main stream (rank 0); ms_per_step is '
                                                          'wall / steps of the pipelined loop'},
